@@ -1,0 +1,405 @@
+#!/usr/bin/env python3
+"""Oracle (test infrastructure): generate tests/golden/*.npz FROM THE REFERENCE'S OWN MODEL FILES.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+It imports /root/reference/models/{char_translator,char_lstm,char_cnn,model_utils}.py unmodified
+through the harness-side shim of SURVEY.md Appendix D (Py2 ``xrange``, ``.cuda()`` -> identity,
+``torch.cuda.*Tensor`` -> CPU tensor types), pins the Gumbel noise by replacing
+``char_translator.sample_gumbel`` with a function that pops pre-generated uniforms and applies the
+reference formula, runs the modules on random-init weights and synthetic ids, and stores
+inputs + state_dicts + outputs + gradients as small .npz files.  The step-level fixture drives
+the reference models with oracle/adv_step.py (the reference driver is Py2-only).
+
+Nothing of the reference's source text is written to the fixtures: they hold arrays and the
+JSON of the params dict only.
+"""
+import builtins
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+warnings.filterwarnings('ignore')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def install_shim():
+    builtins.xrange = range
+    nn.Module.cuda = lambda self, *a, **k: self
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.cuda.IntTensor = torch.IntTensor
+    torch.cuda.ByteTensor = torch.BoolTensor
+    torch.cuda.LongTensor = torch.LongTensor
+    sys.path.insert(0, '/root/reference/models')
+    import model_utils
+    ppu = model_utils.pad_packed_sequence
+    model_utils.pad_packed_sequence = lambda p: (lambda o, l: (o, l.tolist()))(*ppu(p))
+    import char_translator, char_lstm, char_cnn
+    return char_translator, char_lstm, char_cnn, model_utils
+
+
+class Noise(object):
+    """Queue of uniforms; generated on demand with a private generator and recorded."""
+
+    def __init__(self, seed):
+        self.gen = torch.Generator().manual_seed(seed)
+        self.drawn = []
+        self.replay = None
+
+    def sample_gumbel(self, x):
+        if self.replay is not None:
+            u = self.replay.pop(0)
+        else:
+            u = torch.rand(*x.shape, generator=self.gen)
+            self.drawn.append(u.clone())
+        return -torch.log(-torch.log(u + 1e-20) + 1e-20)
+
+
+def sd_np(model, prefix):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def grads_np(model, prefix):
+    out = {}
+    for n, p in model.named_parameters():
+        out[prefix + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().copy()
+    return out
+
+
+def save(name, params, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    arrays['params_json'] = np.array(json.dumps(params))
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('wrote %-32s %7.1f KB' % (name + '.npz', os.path.getsize(path) / 1024.))
+
+
+# dims: H multiple of 64 (the HIP LSTM kernels tile hidden units by 16 and K by 64), odd V,
+# E and batch sizes that are not multiples of anything.
+V0, E0, H0, A0 = 50, 24, 64, 10
+
+
+def gen_params(**over):
+    p = dict(vocabulary_size=V0, embedding_size=E0, enc_hidden_size=H0, dec_hidden_size=H0,
+             enc_hidden_depth=1, dec_hidden_depth=1, en_residual_conn=0, pad_auth_vec=A0,
+             num_output_layers=2, batch_size=999, gumbel_hard=True, softmax_scale=3.0, maxpoolrnn=0,
+             drop_prob_emb=0.0, drop_prob_encoder=0.0, drop_prob_decoder=0.0)
+    p.update(over)
+    return p
+
+
+def eval_params(**over):
+    p = dict(vocabulary_size=V0, embedding_size=E0, hidden_size=H0, hidden_depth=2, en_residual_conn=0,
+             num_output_layers=2, mode='classifier', maxpoolrnn=0, bidir=False,
+             drop_prob_encoder=0.0, drop_prob_decoder=0.0)
+    p.update(over)
+    return p
+
+
+def synth_batch(gen, T, B, V, lens=None, start=2, end=1):
+    """ids ~ randint(3,V); row 0 = START; targets = ids shifted with END appended."""
+    if lens is None:
+        lens = sorted([int(x) for x in torch.randint(3, T + 1, (B,), generator=gen)], reverse=True)
+        lens[0] = T
+    inps = torch.zeros(T, B, dtype=torch.long)
+    targs = torch.zeros(T, B, dtype=torch.long)
+    for b, L in enumerate(lens):
+        body = torch.randint(3, V + 1, (L,), generator=gen)
+        inps[0, b] = start
+        inps[1:L, b] = body[:L - 1]
+        targs[:L - 1, b] = body[:L - 1]
+        targs[L - 1, b] = end
+    return inps, targs, lens
+
+
+def scale_weights(model, factor_W=200.0):
+    """decoder_W init is +-1e-3 (logits nearly flat).  Scale it so that soft-max / argmax paths
+    see well-separated logits; this is 'identical weights' for both sides, so parity is unaffected."""
+    with torch.no_grad():
+        model.decoder_W.mul_(factor_W)
+
+
+# ------------------------------------------------------------------------------------------
+def fx_gumbel(ct):
+    g = torch.Generator().manual_seed(11)
+    for hard in (0, 1):
+        x = torch.randn(6, 37, generator=g) * 2.0
+        x.requires_grad_(True)
+        noise = Noise(5 + hard)
+        ct.sample_gumbel = noise.sample_gumbel
+        y = ct.gumbel_softmax_sample(x, tau=0.5, hard=bool(hard))
+        up = torch.randn(6, 37, generator=g)
+        (y * up).sum().backward()
+        save('gumbel_hard%d' % hard, {'tau': 0.5, 'hard': hard}, x=x, u=noise.drawn[0], y=y, upstream=up, dx=x.grad)
+
+
+def fx_translator_mltrain(ct):
+    cases = {
+        'mltrain_plain': dict(),
+        'mltrain_res2': dict(en_residual_conn=1, enc_hidden_depth=2, dec_hidden_depth=2),
+        'mltrain_deep2': dict(enc_hidden_depth=2, dec_hidden_depth=2),
+        'mltrain_maxpool': dict(maxpoolrnn=1),
+    }
+    for name, over in cases.items():
+        g = torch.Generator().manual_seed(21)
+        torch.manual_seed(3)
+        p = gen_params(**over)
+        m = ct.CharTranslator(p)
+        scale_weights(m, 100.0)
+        m.train()
+        T, B = 7, 5
+        inps, targs, lens = synth_batch(g, T, B, V0)
+        auths = torch.LongTensor([1] * B)
+        scores, _ = m.forward_mltrain(inps, lens, inps, lens, auths=auths)
+        from torch.nn.utils.rnn import pack_padded_sequence as pps
+        loss = nn.functional.cross_entropy(pps(scores, lens)[0], pps(targs, lens)[0])
+        loss.backward()
+        arrs = dict(inps=inps, targs=targs, lens=np.array(lens), auths=auths, scores=scores, loss=loss)
+        arrs.update(sd_np(m, 'sd.'))
+        arrs.update(grads_np(m, 'grad.'))
+        save(name, p, **arrs)
+
+    # soft (adv_inp) encoder input + sort_enc permutation, as the 'ml' cycle pass uses it
+    g = torch.Generator().manual_seed(22)
+    torch.manual_seed(4)
+    p = gen_params()
+    m = ct.CharTranslator(p)
+    scale_weights(m, 100.0)
+    m.train()
+    T, B = 6, 5
+    inps, targs, lens = synth_batch(g, T, B, V0)
+    soft_lens = [7, 6, 6, 4, 2]
+    soft = torch.softmax(torch.randn(7, B, V0 + 1, generator=g) * 3, dim=-1)
+    for b, L in enumerate(soft_lens):
+        soft[L:, b] = 0
+    soft.requires_grad_(True)
+    perm = torch.LongTensor([3, 0, 4, 1, 2])
+    auths = torch.LongTensor([0] * B)
+    scores, _ = m.forward_mltrain(soft, soft_lens, inps, lens, auths=auths, adv_inp=True, sort_enc=perm)
+    from torch.nn.utils.rnn import pack_padded_sequence as pps
+    loss = nn.functional.cross_entropy(pps(scores, lens)[0], pps(targs, lens)[0])
+    loss.backward()
+    arrs = dict(inps=inps, targs=targs, lens=np.array(lens), auths=auths, soft=soft.detach(),
+                soft_lens=np.array(soft_lens), sort_enc=perm, scores=scores, loss=loss, dsoft=soft.grad)
+    arrs.update(sd_np(m, 'sd.'))
+    arrs.update(grads_np(m, 'grad.'))
+    save('mltrain_soft_sortenc', p, **arrs)
+
+
+def fx_advers_gen(ct):
+    for name, over, T, B in (('gen_soft_plain', dict(), 7, 5), ('gen_soft_res2',
+                             dict(en_residual_conn=1, enc_hidden_depth=2, dec_hidden_depth=2), 6, 4)):
+        g = torch.Generator().manual_seed(31)
+        torch.manual_seed(5)
+        p = gen_params(**over)
+        m = ct.CharTranslator(p)
+        scale_weights(m, 300.0)
+        m.train()
+        inps, targs, lens = synth_batch(g, T, B, V0)
+        auths = torch.LongTensor([1] * B)
+        n_max = T + 2
+        # pass 1: no end symbol, to find a token that terminates some rows early
+        noise = Noise(77)
+        ct.sample_gumbel = noise.sample_gumbel
+        s, gl, co = m.forward_advers_gen(inps, lens, soft_samples=True, temp=0.5, n_max=n_max, end_c=-1, auths=auths)
+        end_c = int(co[2][1])
+        # pass 2: same noise, early termination for some rows
+        noise.replay = [u.clone() for u in noise.drawn]
+        m.zero_grad()
+        s, gl, co = m.forward_advers_gen(inps, lens, soft_samples=True, temp=0.5, n_max=n_max, end_c=end_c, auths=auths)
+        samp = torch.stack(list(s), 0)
+        R = torch.randn(samp.shape, generator=g)
+        loss = (samp * R).sum()
+        loss.backward()
+        arrs = dict(inps=inps, lens=np.array(lens), auths=auths, n_max=n_max, end_c=end_c, temp=0.5,
+                    samp=samp, gen_lens=gl, char_outs=torch.stack(list(co), 0), R=R, loss=loss)
+        for i, u in enumerate(noise.drawn):
+            arrs['u%d' % i] = u
+        arrs['n_noise'] = len(noise.drawn)
+        arrs.update(sd_np(m, 'sd.'))
+        arrs.update(grads_np(m, 'grad.'))
+        save(name, p, **arrs)
+
+    # greedy decoding, with top-1/top-2 logit margins so exactness is asserted where meaningful
+    g = torch.Generator().manual_seed(32)
+    torch.manual_seed(6)
+    p = gen_params()
+    m = ct.CharTranslator(p)
+    scale_weights(m, 300.0)
+    m.eval()
+    T, B = 7, 5
+    inps, targs, lens = synth_batch(g, T, B, V0)
+    auths = torch.LongTensor([0] * B)
+    with torch.no_grad():
+        s, gl, co = m.forward_advers_gen(inps, lens, soft_samples=False, n_max=10, end_c=-1, auths=auths)
+        end_c = int(co[3][2])
+        s, gl, co = m.forward_advers_gen(inps, lens, soft_samples=False, n_max=10, end_c=end_c, auths=auths)
+    arrs = dict(inps=inps, lens=np.array(lens), auths=auths, n_max=10, end_c=end_c, gen_lens=gl,
+                char_outs=torch.stack(list(co), 0))
+    arrs.update(sd_np(m, 'sd.'))
+    save('gen_greedy', p, **arrs)
+
+
+def fx_charlstm(cl):
+    from torch.nn.utils.rnn import pack_padded_sequence as pps  # noqa: F401
+    for name, over in (('clf_lstm_mp0', dict()), ('clf_lstm_mp1', dict(maxpoolrnn=1)),
+                       ('clf_lstm_mp2', dict(maxpoolrnn=2)), ('clf_lstm_res', dict(en_residual_conn=1))):
+        g = torch.Generator().manual_seed(41)
+        torch.manual_seed(7)
+        p = eval_params(**over)
+        m = cl.CharLstm(p)
+        m.train()
+        T, B = 7, 5
+        inps, targs, lens = synth_batch(g, T, B, V0)
+        labels = torch.LongTensor([0, 1, 1, 0, 1])
+        logits, feat = m.forward_classify(targs, lens=lens)
+        loss = nn.functional.cross_entropy(logits, labels)
+        loss.backward()
+        arrs = dict(x=targs, lens=np.array(lens), labels=labels, logits=logits, feat=feat, loss=loss)
+        arrs.update(sd_np(m, 'sd.'))
+        arrs.update(grads_np(m, 'grad.'))
+        # soft input path on the same weights
+        m.zero_grad()
+        soft = torch.softmax(torch.randn(T, B, V0 + 1, generator=g) * 3, dim=-1)
+        for b, L in enumerate(lens):
+            soft[L:, b] = 0
+        soft.requires_grad_(True)
+        logits_s, feat_s = m.forward_classify(soft, adv_inp=True, lens=lens, drop=False)
+        loss_s = nn.functional.cross_entropy(logits_s, labels)
+        loss_s.backward()
+        arrs.update(dict(soft=soft.detach(), logits_soft=logits_s, feat_soft=feat_s, loss_soft=loss_s,
+                         dsoft=soft.grad))
+        arrs.update(grads_np(m, 'gradsoft.'))
+        save(name, p, **arrs)
+
+
+def fx_charcnn(cc):
+    for name, over in (('clf_cnn_234', dict(decoder_cnn_ks=[2, 3, 4])),
+                       ('clf_cnn_43', dict(decoder_cnn_ks=[4, 3])),
+                       ('clf_cnn_3layer_res', dict(decoder_cnn_ks=[3, 5], decoder_cnn_nlayers=3,
+                                                   decoder_cnn_residual=1))):
+        g = torch.Generator().manual_seed(51)
+        torch.manual_seed(8)
+        p = dict(vocabulary_size=V0, embedding_size=E0, num_output_layers=2, decoder_cnn_nfilt=12,
+                 drop_prob_encoder=0.0, drop_prob_decoder=0.0, modeltype='cnn')
+        p.update(over)
+        m = cc.CharCNN(p)
+        with torch.no_grad():
+            for layer in m.decoder_cnn:
+                for conv in layer:
+                    conv.weight.mul_(30.0)
+                    conv.bias.uniform_(-0.1, 0.1)
+        m.train()
+        T, B = 9, 5
+        inps, targs, lens = synth_batch(g, T, B, V0)
+        labels = torch.LongTensor([0, 1, 1, 0, 1])
+        logits, feat = m.forward_classify(targs, lens=lens)
+        loss = nn.functional.cross_entropy(logits, labels)
+        loss.backward()
+        arrs = dict(x=targs, lens=np.array(lens), labels=labels, logits=logits, feat=feat, loss=loss)
+        arrs.update(sd_np(m, 'sd.'))
+        arrs.update(grads_np(m, 'grad.'))
+        m.zero_grad()
+        soft = torch.softmax(torch.randn(T, B, V0 + 1, generator=g) * 3, dim=-1)
+        soft.requires_grad_(True)
+        logits_s, feat_s = m.forward_classify(soft, adv_inp=True, lens=lens)
+        loss_s = nn.functional.cross_entropy(logits_s, labels)
+        loss_s.backward()
+        arrs.update(dict(soft=soft.detach(), logits_soft=logits_s, feat_soft=feat_s, loss_soft=loss_s,
+                         dsoft=soft.grad))
+        arrs.update(grads_np(m, 'gradsoft.'))
+        save(name, p, **arrs)
+
+
+def fx_adv_step(ct, cl, cc):
+    from oracle import adv_step
+    for name, clf in (('adv_step_lstm', 'lstm'), ('adv_step_cnn', 'cnn')):
+        g = torch.Generator().manual_seed(61)
+        torch.manual_seed(9)
+        gp = gen_params()
+        modelGen = ct.CharTranslator(gp)
+        scale_weights(modelGen, 300.0)
+        if clf == 'lstm':
+            ep = eval_params()
+            modelEval = cl.CharLstm(ep)
+        else:
+            ep = dict(vocabulary_size=V0, embedding_size=E0, num_output_layers=2, decoder_cnn_nfilt=12,
+                      decoder_cnn_ks=[2, 3, 4], drop_prob_encoder=0.0, drop_prob_decoder=0.0, modeltype='cnn')
+            modelEval = cc.CharCNN(ep)
+            with torch.no_grad():
+                for layer in modelEval.decoder_cnn:
+                    for conv in layer:
+                        conv.weight.mul_(30.0)
+        modelGen.train()
+        modelEval.train()
+        optG, optE = adv_step.make_optimizers(modelGen, modelEval)
+        T, B = 7, 6
+        src = synth_batch(g, T, B, V0)
+        tgt = synth_batch(g, T, B, V0)
+        gb = synth_batch(g, T, B, V0)
+        c_aid = 0
+        mk = lambda b, a: (b[0], b[1], torch.LongTensor([a] * B), b[2])
+        end_c, maxlen, temp = 1, T, 0.5
+        append = torch.zeros(1, B, V0 + 1)
+        append[:, :, 2] = 1.0
+        arrs = {}
+        arrs.update(sd_np(modelGen, 'sdG0.'))
+        arrs.update(sd_np(modelEval, 'sdE0.'))
+        noise = Noise(88)
+        ct.sample_gumbel = noise.sample_gumbel
+        # --- D update
+        rd = adv_step.d_update(modelGen, modelEval, optE, mk(src, c_aid), mk(tgt, 1 - c_aid), c_aid, end_c,
+                               maxlen, temp, step=False)
+        arrs.update(grads_np(modelEval, 'gradE.'))
+        optE.step()
+        arrs.update(sd_np(modelEval, 'sdE1.'))
+        n_noise_d = len(noise.drawn)
+        # --- G update (ml cycle)
+        rg = adv_step.g_update(modelGen, modelEval, optG, mk(gb, c_aid), c_aid, end_c, maxlen, temp, append,
+                               cycle_loss_type='ml', cycle_loss_w=1.0, grad_clip=10.0, step=False)
+        arrs.update(grads_np(modelGen, 'gradG.'))       # after clipping (in place), as the optimizer sees them
+        optG.step()
+        arrs.update(sd_np(modelGen, 'sdG1.'))
+        for k, v in rd.items():
+            arrs['d.' + k] = torch.stack(list(v), 0) if isinstance(v, list) else v
+        for k, v in rg.items():
+            arrs['g.' + k] = torch.stack(list(v), 0) if isinstance(v, list) else v
+        for nm, b in (('src', src), ('tgt', tgt), ('gb', gb)):
+            arrs[nm + '.inps'], arrs[nm + '.targs'], arrs[nm + '.lens'] = b[0], b[1], np.array(b[2])
+        for i, u in enumerate(noise.drawn):
+            arrs['u%d' % i] = u
+        arrs.update(dict(n_noise=len(noise.drawn), n_noise_d=n_noise_d, c_aid=c_aid, end_c=end_c, maxlen=maxlen,
+                         temp=temp, eval_params_json=np.array(json.dumps(ep))))
+        save(name, gp, **arrs)
+
+
+def fx_init(ct, cl):
+    torch.manual_seed(10)
+    m = ct.CharTranslator(gen_params())
+    e = cl.CharLstm(eval_params())
+    save('init_bias', gen_params(),
+         g_enc_bias_ih=m.enc_rec_layers.bias_ih_l0.detach(), g_dec_bias_hh=m.dec_rec_layers.bias_hh_l0.detach(),
+         e_bias_ih_l1=e.rec_layers.bias_ih_l1.detach(),
+         g_decoder_W_absmax=m.decoder_W.detach().abs().max(), e_decoder_W_absmax=e.decoder_W.detach().abs().max())
+
+
+if __name__ == '__main__':
+    ct, cl, cc, mu = install_shim()
+    fx_gumbel(ct)
+    fx_translator_mltrain(ct)
+    fx_advers_gen(ct)
+    fx_charlstm(cl)
+    fx_charcnn(cc)
+    fx_adv_step(ct, cl, cc)
+    fx_init(ct, cl)

@@ -1,0 +1,173 @@
+"""Scenario runners shared by the oracle-vs-golden tests (CPU) and the HIP-vs-golden tests (GPU).
+
+Each runner takes an ``impl`` namespace exposing CharTranslator / CharLstm / CharCNN (the oracle
+package or the HIP-backed package) and a device, replays one golden fixture and asserts parity.
+"""
+import torch
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pack_padded_sequence as pps
+
+from golden_util import Fixture, assert_close, assert_grads_close
+
+MLTRAIN = ['mltrain_plain', 'mltrain_res2', 'mltrain_deep2', 'mltrain_maxpool']
+GEN_SOFT = ['gen_soft_plain', 'gen_soft_res2']
+CLF_LSTM = ['clf_lstm_mp0', 'clf_lstm_mp1', 'clf_lstm_mp2', 'clf_lstm_res']
+CLF_CNN = ['clf_cnn_234', 'clf_cnn_43', 'clf_cnn_3layer_res']
+ADV_STEP = ['adv_step_lstm', 'adv_step_cnn']
+
+
+def _load(model, sd, device):
+    model.to(device)
+    missing = model.load_state_dict({k: v.to(device) for k, v in sd.items()})
+    assert not missing.missing_keys and not missing.unexpected_keys, missing
+    return model
+
+
+def _packed_ce(scores, targs, lens):
+    return F.cross_entropy(pps(scores, lens)[0], pps(targs.to(scores.device), lens)[0])
+
+
+def run_gumbel(impl, device, name, tol):
+    fx = Fixture(name)
+    x = fx.t('x', device).requires_grad_(True)
+    y = impl.gumbel_softmax_sample(x, float(fx.params['tau']), bool(fx.params['hard']),
+                                   impl.NoiseSource(queue=[fx.t('u', device)]))
+    (y * fx.t('upstream', device)).sum().backward()
+    assert_close(y, fx.t('y'), tol, name + ' y')
+    assert_close(x.grad, fx.t('dx'), 5 * tol, name + ' dx')
+
+
+def run_mltrain(impl, device, name, tol_out, tol_grad):
+    fx = Fixture(name)
+    m = _load(impl.CharTranslator(fx.params), fx.group('sd.'), device).train()
+    lens = fx.np('lens').tolist()
+    scores, _ = m.forward_mltrain(fx.t('inps'), lens, fx.t('inps'), lens, auths=fx.t('auths'))
+    loss = _packed_ce(scores, fx.t('targs'), lens)
+    loss.backward()
+    # padded positions hold decoder_b in both implementations; compare everything
+    assert_close(scores, fx.t('scores'), tol_out, name + ' scores')
+    assert_close(loss, fx.t('loss'), tol_out, name + ' loss')
+    assert_grads_close(m.named_parameters(), fx.group('grad.'), tol_grad, name)
+
+
+def run_mltrain_soft(impl, device, tol_out, tol_grad):
+    name = 'mltrain_soft_sortenc'
+    fx = Fixture(name)
+    m = _load(impl.CharTranslator(fx.params), fx.group('sd.'), device).train()
+    lens = fx.np('lens').tolist()
+    soft = fx.t('soft', device).requires_grad_(True)
+    scores, _ = m.forward_mltrain(soft, fx.np('soft_lens').tolist(), fx.t('inps'), lens, auths=fx.t('auths'),
+                                  adv_inp=True, sort_enc=fx.t('sort_enc', device))
+    loss = _packed_ce(scores, fx.t('targs'), lens)
+    loss.backward()
+    assert_close(scores, fx.t('scores'), tol_out, name + ' scores')
+    assert_close(loss, fx.t('loss'), tol_out, name + ' loss')
+    assert_close(soft.grad, fx.t('dsoft'), tol_grad, name + ' dsoft')
+    assert_grads_close(m.named_parameters(), fx.group('grad.'), tol_grad, name)
+
+
+def run_gen_soft(impl, device, name, tol_out, tol_grad):
+    fx = Fixture(name)
+    m = _load(impl.CharTranslator(fx.params), fx.group('sd.'), device).train()
+    m.set_noise(fx.noise_list(device))
+    lens = fx.np('lens').tolist()
+    s, gl, co = m.forward_advers_gen(fx.t('inps'), lens, soft_samples=True, temp=float(fx.scalar('temp')),
+                                     n_max=int(fx.scalar('n_max')), end_c=int(fx.scalar('end_c')),
+                                     auths=fx.t('auths'))
+    samp = torch.stack(list(s), 0)
+    chars = torch.stack(list(co), 0)
+    assert samp.shape == fx.t('samp').shape, (samp.shape, fx.t('samp').shape)
+    assert torch.equal(chars.cpu().long(), fx.t('char_outs').long()), name + ' sampled tokens differ'
+    assert torch.equal(gl.cpu().long(), fx.t('gen_lens').long()), name + ' gen_lens differ'
+    loss = (samp * fx.t('R', device)).sum()
+    loss.backward()
+    assert_close(samp, fx.t('samp'), tol_out, name + ' samples')
+    assert_close(loss, fx.t('loss'), 10 * tol_out, name + ' loss')
+    assert_grads_close(m.named_parameters(), fx.group('grad.'), tol_grad, name)
+
+
+def run_gen_greedy(impl, device):
+    fx = Fixture('gen_greedy')
+    m = _load(impl.CharTranslator(fx.params), fx.group('sd.'), device).eval()
+    with torch.no_grad():
+        s, gl, co = m.forward_advers_gen(fx.t('inps'), fx.np('lens').tolist(), soft_samples=False,
+                                         n_max=int(fx.scalar('n_max')), end_c=int(fx.scalar('end_c')),
+                                         auths=fx.t('auths'))
+    assert len(s) == 0
+    chars = torch.stack(list(co), 0)
+    assert torch.equal(chars.cpu().long(), fx.t('char_outs').long()), 'greedy tokens differ'
+    assert torch.equal(gl.cpu().long(), fx.t('gen_lens').long()), 'greedy gen_lens differ'
+
+
+def _clf(impl, fx):
+    if fx.params.get('modeltype', 'lstm') == 'lstm':
+        return impl.CharLstm(fx.params)
+    return impl.CharCNN(fx.params)
+
+
+def run_classifier(impl, device, name, tol_out, tol_grad):
+    fx = Fixture(name)
+    m = _load(_clf(impl, fx), fx.group('sd.'), device).train()
+    lens = fx.np('lens').tolist()
+    labels = fx.t('labels', device)
+    logits, feat = m.forward_classify(fx.t('x'), lens=lens)
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    assert_close(logits, fx.t('logits'), tol_out, name + ' logits')
+    assert_close(feat, fx.t('feat'), tol_out, name + ' feat')
+    assert_close(loss, fx.t('loss'), tol_out, name + ' loss')
+    assert_grads_close(m.named_parameters(), fx.group('grad.'), tol_grad, name + ' hard')
+    m.zero_grad()
+    soft = fx.t('soft', device).requires_grad_(True)
+    logits, feat = m.forward_classify(soft, adv_inp=True, lens=lens, drop=False)
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    assert_close(logits, fx.t('logits_soft'), tol_out, name + ' logits(soft)')
+    assert_close(loss, fx.t('loss_soft'), tol_out, name + ' loss(soft)')
+    assert_close(soft.grad, fx.t('dsoft'), tol_grad, name + ' dsoft')
+    assert_grads_close(m.named_parameters(), fx.group('gradsoft.'), tol_grad, name + ' soft')
+
+
+def run_adv_step(impl, device, name, tol_out, tol_grad, step_mod=None, tol_weights=None):
+    """D update then G update ('ml' cycle) on the fixture's weights, inputs and noise."""
+    fx = Fixture(name)
+    step_mod = step_mod or impl
+    # RMSprop's first step is ~ lr * 10 * sign(g): it amplifies rounding noise on near-zero gradient
+    # elements, so the post-step weights get their own (looser) tolerance on the HIP path.
+    tol_weights = tol_weights if tol_weights is not None else tol_grad
+    ep = fx.json('eval_params_json')
+    G = _load(impl.CharTranslator(fx.params), fx.group('sdG0.'), device).train()
+    E = _load(impl.CharLstm(ep) if ep.get('modeltype', 'lstm') == 'lstm' else impl.CharCNN(ep),
+              fx.group('sdE0.'), device).train()
+    optG, optE = step_mod.make_optimizers(G, E)
+    G.set_noise(fx.noise_list(device))
+    B = fx.t('src.inps').shape[1]
+    c_aid = int(fx.scalar('c_aid'))
+    end_c, maxlen, temp = int(fx.scalar('end_c')), int(fx.scalar('maxlen')), float(fx.scalar('temp'))
+    mk = lambda nm, a: (fx.t(nm + '.inps'), fx.t(nm + '.targs'), torch.LongTensor([a] * B),
+                        fx.np(nm + '.lens').tolist())
+    rd = step_mod.d_update(G, E, optE, mk('src', c_aid), mk('tgt', 1 - c_aid), c_aid, end_c, maxlen, temp,
+                           step=False)
+    assert torch.equal(torch.stack(list(rd['char_outs']), 0).cpu().long(), fx.t('d.char_outs').long())
+    assert_close(rd['fake_logits'], fx.t('d.fake_logits'), tol_out, name + ' D fake logits')
+    assert_close(rd['real_logits'], fx.t('d.real_logits'), tol_out, name + ' D real logits')
+    assert_close(rd['loss'], fx.t('d.loss'), tol_out, name + ' D loss')
+    assert_grads_close(E.named_parameters(), fx.group('gradE.'), tol_grad, name + ' D')
+    optE.step()
+    for k, v in fx.group('sdE1.').items():
+        assert_close(E.state_dict()[k], v, tol_weights, name + ' D weights after step: ' + k)
+    # continue from the fixture's exact post-step discriminator so G errors do not compound D ones
+    E.load_state_dict({k: v.to(device) for k, v in fx.group('sdE1.').items()})
+    append = torch.zeros(1, B, fx.params['vocabulary_size'] + 1, device=device)
+    append[:, :, 2] = 1.0
+    rg = step_mod.g_update(G, E, optG, mk('gb', c_aid), c_aid, end_c, maxlen, temp, append,
+                           cycle_loss_type='ml', cycle_loss_w=1.0, grad_clip=10.0, step=False)
+    assert torch.equal(torch.stack(list(rg['char_outs']), 0).cpu().long(), fx.t('g.char_outs').long())
+    assert torch.equal(rg['gen_lens'].cpu().long(), fx.t('g.gen_lens').long())
+    assert_close(rg['loss_gan'], fx.t('g.loss_gan'), tol_out, name + ' G gan loss')
+    assert_close(rg['cyc_loss'], fx.t('g.cyc_loss'), tol_out, name + ' G cycle loss')
+    assert_close(rg['grad_norm'], fx.t('g.grad_norm'), tol_grad, name + ' G grad norm')
+    assert_grads_close(G.named_parameters(), fx.group('gradG.'), tol_grad, name + ' G')
+    optG.step()
+    for k, v in fx.group('sdG1.').items():
+        assert_close(G.state_dict()[k], v, tol_weights, name + ' G weights after step: ' + k)

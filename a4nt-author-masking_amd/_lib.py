@@ -1,0 +1,78 @@
+"""ctypes binding of liba4nt_hip.so (declared in include/a4nt_hip.h).
+
+The product path has no CPU fallback: a missing library or a non-gfx950 device raises.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_uint, c_float, c_longlong, c_ulonglong, c_void_p, c_char_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liba4nt_hip.so')
+
+P = c_void_p
+_SIGS = {
+    'a4nt_last_error': (c_char_p, []),
+    'a4nt_version': (c_int, []),
+    'a4nt_init': (c_int, [c_int, POINTER(c_int)]),
+    'a4nt_sgemm': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int,
+                           c_longlong, P]),
+    'a4nt_lstm_geometry': (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'a4nt_lstm_xch_floats': (c_longlong, [c_int, c_int, c_int]),
+    'a4nt_lstm_sync_words': (c_int, [c_int, c_int]),
+    'a4nt_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'a4nt_lstm_seq_bwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'a4nt_lstm_check_timeout': (c_int, [P, c_int, P]),
+    'a4nt_lstm_dec_step': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
+    'a4nt_lstm_cell_bwd': (c_int, [c_int, c_int, P, P, P, P, P, P, P, P]),
+    'a4nt_gumbel_fwd': (c_int, [c_int, c_int, P, c_int, P, c_int, c_ulonglong, c_uint, c_float, c_float, c_int, c_int,
+                                P, c_int, P, P, P, P, P, P, c_longlong, P, c_int, P]),
+    'a4nt_gumbel_bwd': (c_int, [c_int, c_int, P, c_int, P, c_int, P, c_float, P]),
+    'a4nt_nll_rows': (c_int, [c_int, c_int, P, c_int, P, c_float, P, c_int, P]),
+    'a4nt_embed_fwd': (c_int, [c_longlong, c_int, c_int, P, P, P, P, c_int, P]),
+    'a4nt_embed_bwd': (c_int, [c_longlong, c_int, c_int, P, P, P, c_int, P, c_longlong, P]),
+    'a4nt_colsum': (c_int, [c_int, c_int, P, c_int, P, c_int, P]),
+    'a4nt_slab_reduce': (c_int, [c_int, c_longlong, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, P]),
+    'a4nt_lrelu_maxtime': (c_int, [c_int, c_int, c_int, P, c_int, c_float, c_int, P, c_int, P, P]),
+    'a4nt_lrelu_maxtime_bwd': (c_int, [c_int, c_int, c_int, P, c_int, c_float, P, c_int, P, P]),
+}
+EXPORTS = sorted(_SIGS)
+
+_lib = None
+
+
+class A4NTError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise A4NTError('%s not found: build it with a4nt-author-masking_amd/csrc/build.sh (or __graft_entry__.build()); '
+                        'there is no CPU fallback for the HIP path' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().a4nt_last_error().decode('utf-8', 'replace')
+        raise A4NTError('%s failed (code %d): %s' % (what or 'a4nt call', rc, msg))
+
+
+_inited = set()
+
+
+def init_device(index):
+    if index in _inited:
+        return
+    ncu = c_int(0)
+    check(load().a4nt_init(int(index), ctypes.byref(ncu)), 'a4nt_init')
+    _inited.add(index)

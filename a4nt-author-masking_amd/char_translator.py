@@ -1,0 +1,290 @@
+"""HIP-backed CharTranslator: the reference's seq2seq generator (models/char_translator.py:30-401)
+with the same constructor, params dict, method signatures and state_dict keys, computing through
+liba4nt_hip.so (persistent LSTM sweeps, MFMA GEMMs, fused Gumbel / NLL row kernels).
+
+Inputs follow the reference's conventions: token ids arrive as CPU int64 [T,B] tensors, lengths as
+Python lists, `auths` as a CPU LongTensor; outputs are CUDA tensors attached to autograd.
+Extensions (used by this package's own adversarial step, not required by reference callers):
+  * forward_advers_gen(..., compact=True) returns the samples as a SoftSamples (token, value) pair
+    instead of a list of dense [B,V] rows;
+  * every method that takes a dense soft input [T,B,V] also takes a SoftSamples;
+  * forward_mltrain_loss fuses the vocab projection with log-softmax/NLL (the reference's callers
+    compute CrossEntropyLoss on the returned [T,B,V] scores themselves);
+  * set_noise(list) pins the Gumbel uniforms for parity tests (the reference draws from the global
+    CUDA RNG, char_translator.py:11); otherwise an on-device Philox stream keyed by `noise_seed`.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .gen_decode import SoftSamples, sample_embed, gen_decode
+from .model_utils import (build_rec, rec_layer_params, fill_forget_bias, lens_to_device, run_stack, packed_mean,
+                          check_hidden)
+
+_UNSUPPORTED = ['split_generators', 'learn_gumbel', 'no_encoder', 'apply_noise']
+
+
+class CharTranslator(nn.Module):
+    def __init__(self, params, encoder_only=False):
+        super().__init__()
+        for k in _UNSUPPORTED:
+            if params.get(k, 0):
+                raise NotImplementedError('a4nt_amd.CharTranslator: option %r is outside the hot-path scope' % k)
+        self.encoder_only = encoder_only
+        self.encoder_mean_vec = params.get('encoder_mean_vec', 0)
+        self.vocab_size = params.get('vocabulary_size', -1) + 1
+        self.enc_num_rec_layers = params.get('enc_hidden_depth', -1)
+        self.emb_size = params.get('embedding_size', -1)
+        self.enc_hidden_size = params.get('enc_hidden_size', -1)
+        self.dec_num_rec_layers = params.get('dec_hidden_depth', -1)
+        self.dec_hidden_size = params.get('dec_hidden_size', -1)
+        self.en_residual = params.get('en_residual_conn', 1)
+        self.pad_auth_vec = params.get('pad_auth_vec', 0)
+        self.gumb_type = params.get('gumbel_hard', False)
+        self.softmax_scale = params.get('softmax_scale', 2.0)
+        self.max_pool_rnn = params.get('maxpoolrnn', 0)
+        self.temp = None
+        check_hidden(self.enc_hidden_size, 'enc_hidden_size')
+
+        # construction order follows the reference so that a torch seed gives the same weights
+        if self.pad_auth_vec:
+            self.auth_emb = nn.Embedding(params.get('num_output_layers', 2), self.pad_auth_vec)
+        self.char_emb = nn.Embedding(self.vocab_size, self.emb_size, padding_idx=0)
+        self.p_emb = params.get('drop_prob_emb', 0.25)
+        self.enc_rec_layers = build_rec(self.emb_size, self.enc_hidden_size, self.enc_num_rec_layers, self.en_residual)
+        self.p_enc = params.get('drop_prob_encoder', 0.25)
+        if not encoder_only:
+            check_hidden(self.dec_hidden_size, 'dec_hidden_size')
+            self.ctx_size = self.enc_hidden_size * (1 + self.max_pool_rnn) + self.pad_auth_vec
+            self.dec_rec_layers = build_rec(self.ctx_size + self.emb_size, self.dec_hidden_size,
+                                            self.dec_num_rec_layers, self.en_residual)
+            self.decoder_W = nn.Parameter(torch.zeros(self.dec_hidden_size, self.vocab_size))
+            self.decoder_b = nn.Parameter(torch.zeros(self.vocab_size))
+            self.p_dec = params.get('drop_prob_decoder', 0.25)
+        self.init_weights()
+        self.zero_hidden_bsz = params['batch_size']
+        self._noise = None
+        self.noise_seed = int(params.get('noise_seed', 0))
+        self._noise_step = 0
+        dev = params.get('device', 'cuda')
+        self.to(dev)
+        ops._lib.init_device(self.char_emb.weight.device.index or 0)
+
+    def init_weights(self):
+        with torch.no_grad():
+            if not self.encoder_only:
+                self.decoder_W.uniform_(-0.001, 0.001)
+                self.decoder_b.zero_()
+        fill_forget_bias(self.enc_rec_layers, self.en_residual, self.enc_num_rec_layers, self.enc_hidden_size, 1.0)
+        if not self.encoder_only:
+            fill_forget_bias(self.dec_rec_layers, self.en_residual, self.dec_num_rec_layers, self.dec_hidden_size, 1.0)
+
+    # ------------------------------------------------------------------------------------------
+    def set_noise(self, uniforms):
+        """Pin the Gumbel uniforms: one [B,V] CUDA tensor per sampling step, consumed in order."""
+        self._noise = list(uniforms) if uniforms is not None else None
+
+    def _dev(self):
+        return self.char_emb.weight.device
+
+    def init_hidden(self, bsz):
+        w = self.char_emb.weight
+        return (w.new_zeros(self.enc_num_rec_layers, bsz, self.enc_hidden_size),
+                w.new_zeros(self.enc_num_rec_layers, bsz, self.enc_hidden_size))
+
+    def init_hidden_dec(self, bsz):
+        w = self.char_emb.weight
+        return (w.new_zeros(self.dec_num_rec_layers, bsz, self.dec_hidden_size),
+                w.new_zeros(self.dec_num_rec_layers, bsz, self.dec_hidden_size))
+
+    def _drop(self, x, p):
+        return F.dropout(x, p, True) if (self.training and p > 0.0) else x
+
+    def _embed_input(self, x, adv_inp, drop):
+        """Hard ids -> nn.Embedding (+ emb dropout when `drop`); soft input -> samples * char_emb.weight
+        (no dropout, char_translator.py:212-214)."""
+        if isinstance(x, SoftSamples):
+            return sample_embed(x, self.char_emb.weight)
+        if adv_inp:
+            T, B = x.shape[0], x.shape[1]
+            return ops.linear_kn(x.reshape(T * B, -1), self.char_emb.weight).view(T, B, -1)
+        emb = ops.embedding(x.to(self._dev()), self.char_emb.weight, 0)
+        return self._drop(emb, self.p_emb) if drop else emb
+
+    def _encode(self, emb, lengths, h_prev):
+        T = emb.shape[0]
+        lens_dev = lens_to_device(lengths, T, emb.device)
+        out, hidden = run_stack(self.enc_rec_layers, emb, lens_dev, self.enc_num_rec_layers, self.en_residual, h_prev)
+        return out, hidden
+
+    # -- teacher forced (char_translator.py:200-286) -------------------------------------------
+    def _mltrain_hidden(self, inp, lengths_inp, targ, lengths_targ, h_prev, auths, adv_inp, sort_enc):
+        dev = self._dev()
+        soft = adv_inp or isinstance(inp, SoftSamples)
+        T_in, B = inp.shape[0], inp.shape[1]
+        emb = self._embed_input(inp, soft, drop=True)
+        enc_out, enc_hidden = self._encode(emb, lengths_inp, h_prev)
+        if self.max_pool_rnn:
+            # reference: plain mean over the padded time axis of the UNPACKED output, whose length is
+            # max(lengths_inp) (char_translator.py:223-228)
+            t_eff = max(int(l) for l in lengths_inp)
+            ctxt = torch.cat([enc_out[:t_eff].mean(dim=0), enc_hidden[0][-1]], dim=-1)
+        else:
+            ctxt = enc_hidden[0][-1]
+        if sort_enc is not None:
+            ctxt = ctxt.index_select(0, sort_enc.to(dev))
+        if self.pad_auth_vec:
+            ctxt = torch.cat([ctxt, self.auth_emb(auths.to(dev))], dim=-1)
+        ctxt = self._drop(ctxt, self.p_enc)
+
+        targ = targ.to(dev)
+        targ_emb = self._drop(ops.embedding(targ, self.char_emb.weight, 0), self.p_emb)
+        n_t = targ.shape[0]
+        lens_dev = lens_to_device(lengths_targ, n_t, dev)
+        # decoder input is [ctxt, emb_t]: the ctxt half of the input contraction is loop invariant
+        w_ih0 = rec_layer_params(self.dec_rec_layers, self.en_residual, 0)[0]
+        gc = ops.linear_nk(ctxt, w_ih0[:, :self.ctx_size])
+        dec_out, dec_hidden = run_stack(self.dec_rec_layers, targ_emb, lens_dev, self.dec_num_rec_layers,
+                                        self.en_residual, None, gc0=gc, w_ih0=w_ih0[:, self.ctx_size:].contiguous())
+        n_eff = max(int(l) for l in lengths_targ)
+        dec_out = self._drop(dec_out[:n_eff], self.p_dec)
+        return dec_out, n_eff, B, (enc_hidden, dec_hidden)
+
+    def forward_mltrain(self, inp, lengths_inp, targ, lengths_targ, h_prev=None, compute_softmax=False, auths=None,
+                        adv_inp=False, sort_enc=None, adv_targ=False):
+        if adv_targ:
+            raise NotImplementedError('adv_targ (language-model loss) is outside the hot-path scope')
+        dec_out, n_t, B, hidden = self._mltrain_hidden(inp, lengths_inp, targ, lengths_targ, h_prev, auths, adv_inp,
+                                                       sort_enc)
+        score = ops.linear_kn(dec_out.reshape(n_t * B, -1), self.decoder_W, self.decoder_b)
+        if compute_softmax:
+            score = F.log_softmax(score, dim=1)
+        return score.view(n_t, B, self.vocab_size), hidden
+
+    def forward_mltrain_loss(self, inp, lengths_inp, targ_in, lengths_targ, targ_out, auths=None, adv_inp=False,
+                             sort_enc=None, h_prev=None):
+        """CrossEntropyLoss(pack(forward_mltrain(...)[0], lens), pack(targ_out, lens)) with the vocab
+        projection fused into the log-softmax/NLL kernel (train_translator.py:111-113;
+        train_adversarial_translator.py:176-177,661-664)."""
+        dec_out, n_t, B, _ = self._mltrain_hidden(inp, lengths_inp, targ_in, lengths_targ, h_prev, auths, adv_inp,
+                                                  sort_enc)
+        dev = self._dev()
+        tgt = targ_out[:n_t].to(dev).clone()
+        steps = torch.arange(n_t, device=dev).view(-1, 1)
+        lens_t = torch.as_tensor([int(l) for l in lengths_targ], device=dev).view(1, -1)
+        tgt[steps >= lens_t] = -1
+        n_valid = int(sum(min(int(l), n_t) for l in lengths_targ))
+        return ops.proj_nll(dec_out.reshape(n_t * B, -1), self.decoder_W, self.decoder_b, tgt.view(-1), n_valid)
+
+    # -- encoder only (char_translator.py:288-312) ----------------------------------------------
+    def forward_encode(self, x, lengths_inp, h_prev=None, adv_inp=False):
+        emb = self._embed_input(x, adv_inp, drop=False)
+        enc_out, enc_hidden = self._encode(emb, lengths_inp, h_prev)
+        if self.encoder_mean_vec:
+            return torch.cat([packed_mean(enc_out, lengths_inp, emb.shape[0]), enc_hidden[0][-1]], dim=-1)
+        return enc_hidden[0][-1]
+
+    # -- free running generation (char_translator.py:314-401) -----------------------------------
+    def forward_advers_gen(self, x, lengths_inp, h_prev=None, n_max=100, end_c=-1, soft_samples=False, temp=0.1,
+                           auths=None, adv_inp=False, n_samples=1, compact=False):
+        dev = self._dev()
+        soft_in = adv_inp or isinstance(x, SoftSamples)
+        B = x.shape[1]
+        emb = self._embed_input(x, soft_in, drop=False)
+        enc_out, enc_hidden = self._encode(emb, lengths_inp, h_prev)
+        if self.max_pool_rnn:
+            ctxt = torch.cat([packed_mean(enc_out, lengths_inp, emb.shape[0]), enc_hidden[0][-1]], dim=-1)
+        else:
+            ctxt = enc_hidden[0][-1]
+        if self.pad_auth_vec:
+            ctxt = torch.cat([ctxt, self.auth_emb(auths.to(dev))], dim=-1)
+        if soft_samples:
+            self.temp = temp
+        fused = (self.dec_num_rec_layers == 1 and not soft_in and n_samples == 1 and
+                 (self.gumb_type or not soft_samples))
+        if not fused:
+            return self._advers_gen_generic(x, soft_in, ctxt, n_max, end_c, soft_samples, temp, n_samples, compact)
+        w_ih, w_hh, b_ih, b_hh = rec_layer_params(self.dec_rec_layers, self.en_residual, 0)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        cfg = dict(n_max=n_max, end_c=int(end_c), tau=float(temp), scale=float(self.softmax_scale),
+                   hard=bool(self.gumb_type), greedy=not soft_samples, need_grad=need_grad, noise=self._noise,
+                   seed=self.noise_seed, step0=self._noise_step)
+        samples, gen_lens, tok = gen_decode(ctxt, x[0].to(dev), self.char_emb.weight, w_ih, w_hh, b_ih, b_hh,
+                                            self.decoder_W, self.decoder_b, cfg)
+        self._noise_step += n_max
+        char_out = list(tok.unbind(0))
+        if not soft_samples:
+            return [], gen_lens, char_out
+        if compact:
+            return samples, gen_lens, char_out
+        return list(samples.to_dense().unbind(0)), gen_lens, char_out
+
+    def _advers_gen_generic(self, x, soft_in, ctxt, n_max, end_c, soft_samples, temp, n_samples, compact):
+        """Step-by-step composition of the same HIP operators (stacked / residual decoders, soft
+        (non straight-through) samples, soft encoder input, n_samples > 1): follows the reference loop
+        literally, including its per-step host check."""
+        if compact:
+            raise NotImplementedError('compact samples need the fused path (1-layer decoder, gumbel_hard, hard input)')
+        dev = self._dev()
+        B = x.shape[1]
+        if isinstance(x, SoftSamples):
+            targ_emb = x.val[0].view(-1, 1) * ops.embedding(x.tok[0], self.char_emb.weight, -1)
+        elif soft_in:
+            targ_emb = ops.linear_kn(x[0], self.char_emb.weight)
+        else:
+            targ_emb = ops.embedding(x[0].to(dev), self.char_emb.weight, 0)
+        dec_bsz = B * n_samples
+        ctxt_rep = ctxt.repeat(n_samples, 1)
+        dec_inp = torch.cat([ctxt, targ_emb], dim=-1).repeat(n_samples, 1)
+        out, dec_hidden = run_stack(self.dec_rec_layers, dec_inp.view(1, dec_bsz, -1), None, self.dec_num_rec_layers,
+                                    self.en_residual, None)
+        p_rnn = out.view(dec_bsz, -1)
+        char_out, samp_out = [], []
+        gen_lens = torch.zeros(dec_bsz, dtype=torch.int32, device=dev)
+        prev_done = torch.zeros(dec_bsz, dtype=torch.bool, device=dev)
+        for _ in range(n_max):
+            dec_out = ops.linear_kn(p_rnn, self.decoder_W, self.decoder_b)
+            if soft_samples:
+                U = self._noise.pop(0) if self._noise is not None else None
+                samp, pred_c = ops.gumbel_dense(dec_out * self.softmax_scale, U, self.noise_seed, self._noise_step,
+                                                float(temp), bool(self.gumb_type))
+                self._noise_step += 1
+                emb = ops.linear_kn(samp, self.char_emb.weight)
+                char_out.append(pred_c)
+                samp.data.masked_fill_(prev_done.view(-1, 1), 0.)      # char_translator.py:384
+                samp_out.append(samp)
+            else:
+                pred_c = _greedy_argmax(dec_out)
+                char_out.append(pred_c)
+                emb = ops.embedding(pred_c, self.char_emb.weight, 0)
+            gen_lens += (~prev_done).int()
+            prev_done = prev_done | (pred_c == end_c)
+            if bool(prev_done.all()):
+                break
+            dec_inp = torch.cat([ctxt_rep, emb], dim=-1).view(1, dec_bsz, -1)
+            out, dec_hidden = run_stack(self.dec_rec_layers, dec_inp, None, self.dec_num_rec_layers, self.en_residual,
+                                        dec_hidden)
+            p_rnn = out.view(dec_bsz, -1)
+        return samp_out, gen_lens, char_out
+
+    def forward_gen(self, x, h_prev=None, auths=None, n_max=100, end_c=-1, soft_samples=False, temp=0.1):
+        """B = 1 sampler of the reference's demo script (char_translator.py:403-469); greedy only (the
+        reference's soft branch is broken: pred_c undefined, :452-461)."""
+        if soft_samples:
+            raise NotImplementedError('forward_gen(soft_samples=True) is broken in the reference; not provided')
+        was_training = self.training
+        self.eval()
+        with torch.no_grad():
+            _, gl, co = self.forward_advers_gen(x, [x.shape[0]] * x.shape[1], n_max=n_max, end_c=end_c,
+                                                soft_samples=False, auths=auths)
+        self.train(was_training)
+        n = int(gl.max().item())
+        return co[:n]
+
+
+def _greedy_argmax(logits):
+    B, V = logits.shape
+    tok = torch.empty(B, dtype=torch.int64, device=logits.device)
+    ops.gumbel_rows(logits.contiguous(), None, 0, 0, 1.0, 1.0, 1, 1, None, None, tok, None, None, None, None, -1)
+    return tok

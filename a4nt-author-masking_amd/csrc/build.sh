@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds liba4nt_hip.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh [-j N]
+set -e
+cd "$(dirname "$0")"
+ARCH=gfx950
+FLAGS="-O3 -std=c++17 --offload-arch=$ARCH -fPIC -fno-gpu-rdc -Wno-unused-result"
+OBJS=""
+pids=()
+for f in capi sgemm lstm rows misc; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ]; then
+    hipcc $FLAGS -c $f.hip -o $f.o &
+    pids+=($!)
+  fi
+  OBJS="$OBJS $f.o"
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=$ARCH -shared -fPIC -o ../liba4nt_hip.so $OBJS
+echo "built $(cd .. && pwd)/liba4nt_hip.so"

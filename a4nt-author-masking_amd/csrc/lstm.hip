@@ -1,0 +1,544 @@
+// Persistent LSTM sweeps for gfx950: recurrent weights resident in VGPRs across all timesteps,
+// recurrent gate contraction on v_mfma_f32_16x16x4_f32 (exact f32), gate non-linearity / cell
+// update fused behind it, hidden state exchanged between workgroups through L2 with write-through
+// stores and an agent-scope arrival counter (common.h).
+//
+// Decomposition (forward).  The batch is cut into G independent row groups of R = 16*MT rows;
+// group g is served by NW = H/16 workgroups, workgroup j owning hidden units [16j, 16j+16), i.e.
+// the 64 gate columns {gate*H + 16j + n}.  Inside a workgroup wave w owns the K quarter
+// [w*H/4, (w+1)*H/4) of the contraction and keeps W_hh[those 64 rows][that quarter] as MFMA
+// B operands in registers (H/4 VGPRs: 128 at H = 512).  Per step each wave pulls its quarter of
+// h_{t-1} for the group's rows straight into MFMA A fragments (1 KiB coalesced sc1 loads of the
+// 16x16 blocks the owning workgroups published), multiplies, and the four partial 16x64 gate
+// tiles are summed through LDS by the cell-update threads (one (row, unit) pair each), which add
+// the precomputed input gates, apply sigmoid/tanh, update c (kept in a register for the whole
+// sweep), emit h_t / the saved activations, and publish the workgroup's 16x16 h block for the
+// next step.  Only the NW workgroups of one group synchronise with each other; groups never do.
+//
+// Backward is the mirror image: workgroup j owns dh columns [16j, 16j+16), wave w owns gate w's
+// H rows of W_hh (K = 4H split over the 4 waves), the exchanged quantity is dgates_t.
+//
+// Sequences of different lengths: a row simply freezes (state kept, output zero, gradient zero)
+// once t >= len[row]; no sorting or packing is needed by the kernels.
+#include "common.h"
+
+#define PSTR 68   // LDS row stride (floats) of the partial gate tiles: conflict-free MFMA-layout stores
+
+struct LstmFwdArgs {
+    int T, B, H, G, NW;
+    const float* gx;        // [T][B][4H] input-gate pre-activations (biases included)
+    const float* whh;       // [4H][H]
+    const float* h0;        // [B][H] or null
+    const float* c0;        // [B][H] or null
+    const int* lens;        // [B] or null
+    const float* cg;        // decode: [B][4H] loop-invariant part of the input gates
+    const float* ptab;      // decode: [V][4H] per-token input-gate table (E * W_ie^T)
+    const long long* tok;   // decode: [B]
+    const float* val;       // decode: [B] straight-through sample value (scales the table row)
+    float* hs;              // [T][B][H]
+    float* gates;           // [T][B][4H] post-activation gates (may alias gx) or null
+    float* cs;              // [T][B][H] or null
+    float* hN; float* cN;   // [B][H] or null
+    float* hx;              // exchange [2][G][NW][MT][256]
+    unsigned* sync;         // [G] counters, 32 words apart, + timeout word at sync[32*G]
+    int mode;               // 0: persistent sequence sweep, 1: single decode step
+    int step0;              // decode: absolute step index (selects the exchange parity)
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float part[4][MT][16 * PSTR];
+    __shared__ __attribute__((aligned(16))) float hstage[MT][256];
+    __shared__ int s_ok;
+
+    const int g = blockIdx.x % a.G, j = blockIdx.x / a.G;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int H = a.H, H4 = 4 * a.H;
+    const int nj = H >> 6;                 // 16-wide k blocks in this wave's K quarter
+    const int u0 = 16 * j;
+    const int r0 = g * 16 * MT;
+    const int fr = lane & 15, fq = lane >> 4;      // MFMA fragment row/col and k-quad
+    const int crow = tid >> 4, cunit = tid & 15;   // cell-update (row, unit) of this thread
+
+    // ---- recurrent weights -> registers --------------------------------------------------
+    f32x4 wreg[8][4];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (jj < nj)
+                t = *reinterpret_cast<const f32x4*>(a.whh + (long long)(gt * H + u0 + fr) * H + w * (H >> 2) + 16 * jj + 4 * fq);
+            wreg[jj][gt] = t;
+        }
+
+    unsigned* ctr = a.sync + 32 * g;
+    unsigned* tmo = a.sync + 32 * a.G;
+    const unsigned blk_bytes = 256 * 4;
+    const long long hx_par = (long long)a.G * a.NW * MT * 256;   // floats per parity buffer
+    __amdgpu_buffer_rsrc_t rs = make_rsrc(a.hx, (unsigned)(2 * hx_par * 4));
+
+    // ---- per-thread recurrent state --------------------------------------------------------
+    float c_reg[MT], h_reg[MT];
+    int len_r[MT];
+    int Tg = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int rb = r0 + 16 * mt + crow;
+        const bool rv = rb < a.B;
+        c_reg[mt] = (rv && a.c0) ? a.c0[(long long)rb * H + u0 + cunit] : 0.f;
+        h_reg[mt] = (rv && a.h0) ? a.h0[(long long)rb * H + u0 + cunit] : 0.f;
+        len_r[mt] = rv ? (a.lens ? min(a.lens[rb], a.T) : a.T) : 0;
+    }
+    if (a.lens) {
+        for (int r = 0; r < 16 * MT; ++r) {
+            const int rb = r0 + r;
+            if (rb < a.B) Tg = max(Tg, min(a.lens[rb], a.T));
+        }
+    } else {
+        Tg = a.T;
+    }
+
+    // optional loop-invariant input-gate term (sequence mode): gates_x[t][b] = gx[t][b] + cg[b]
+    float cgv[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int rb = r0 + 16 * mt + crow;
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+            cgv[mt][gt] = (a.mode == 0 && a.cg && rb < a.B) ? a.cg[(long long)rb * H4 + gt * H + u0 + cunit] : 0.f;
+    }
+
+    int par_r = 0;
+    if (a.mode == 0) {
+        // publish h0 as "step -1" into parity 0
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hstage[mt][crow * 16 + cunit] = h_reg[mt];
+        __syncthreads();
+        if (w < MT) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&hstage[w][4 * lane]);
+            const long long blk = ((long long)(0 * a.G + g) * a.NW + j) * MT + w;
+            st16_sc1(rs, (unsigned)(blk * blk_bytes + lane * 16), v);
+            drain_vmem();
+        }
+        __syncthreads();
+        if (tid == 0) add_flag(ctr, 1u);
+    } else {
+        par_r = a.step0 & 1;
+    }
+
+    for (int t = 0; t < Tg; ++t) {
+        const int par_w = par_r ^ 1;
+        // (a) input gates of this step for the cell-update threads (independent of h: issue early)
+        float xg[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rb = r0 + 16 * mt + crow;
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) xg[mt][gt] = 0.f;
+            if (rb < a.B) {
+                if (a.mode == 0) {
+                    const float* p = a.gx + ((long long)t * a.B + rb) * H4 + u0 + cunit;
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) xg[mt][gt] = p[gt * H] + cgv[mt][gt];
+                } else {
+                    const float* pc = a.cg + (long long)rb * H4 + u0 + cunit;
+                    const float* pt = a.ptab + a.tok[rb] * (long long)H4 + u0 + cunit;
+                    const float vv = a.val[rb];
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) xg[mt][gt] = pc[gt * H] + vv * pt[gt * H];
+                }
+            }
+        }
+        // (b) wait until every workgroup of the group has published h_{t-1}
+        if (a.mode == 0) {
+            if (tid == 0) s_ok = wait_ge(ctr, (unsigned)(a.NW * (t + 1)), tmo) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) break;
+        }
+        // (c)+(d) A fragments straight from the exchange buffer, recurrent MFMA
+        f32x4 acc[4][MT];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[gt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 af[8][MT];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                af[jj][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (jj < nj) {
+                    const long long blk = ((long long)(par_r * a.G + g) * a.NW + (w * nj + jj)) * MT + mt;
+                    af[jj][mt] = ld16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + fq * 4) * 4));
+                }
+            }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            if (jj < nj) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[gt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[jj][mt][i], wreg[jj][gt][i], acc[gt][mt], 0, 0, 0);
+            }
+        }
+        // (e) partial gate tiles -> LDS   (C layout: col = lane&15, row = 4*(lane>>4) + reg)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part[w][mt][(4 * fq + i) * PSTR + gt * 16 + fr] = acc[gt][mt][i];
+        __syncthreads();
+        // (f) cell update, one (row, unit) per thread and row tile
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rb = r0 + 16 * mt + crow;
+            float pre[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) {
+                const int o = crow * PSTR + gt * 16 + cunit;
+                pre[gt] = xg[mt][gt] + ((part[0][mt][o] + part[1][mt][o]) + (part[2][mt][o] + part[3][mt][o]));
+            }
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+            const float cn = fg * c_reg[mt] + ig * gg;
+            const float hn = og * tanhf_(cn);
+            const bool active = t < len_r[mt];
+            if (active) { c_reg[mt] = cn; h_reg[mt] = hn; }
+            if (rb < a.B) {
+                const long long o = ((long long)t * a.B + rb);
+                a.hs[o * H + u0 + cunit] = active ? hn : 0.f;
+                if (a.gates) {
+                    float* pg = a.gates + o * H4 + u0 + cunit;
+                    pg[0] = ig; pg[H] = fg; pg[2 * H] = gg; pg[3 * H] = og;
+                }
+                if (a.cs) a.cs[o * H + u0 + cunit] = cn;
+            }
+            hstage[mt][crow * 16 + cunit] = h_reg[mt];
+        }
+        __syncthreads();
+        // (g) publish this workgroup's h block(s) for step t+1
+        if (w < MT) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&hstage[w][4 * lane]);
+            const long long blk = ((long long)(par_w * a.G + g) * a.NW + j) * MT + w;
+            st16_sc1(rs, (unsigned)(blk * blk_bytes + lane * 16), v);
+            drain_vmem();
+        }
+        __syncthreads();
+        if (a.mode == 0 && tid == 0) add_flag(ctr, 1u);
+        par_r = par_w;
+    }
+
+    // final states and zero tail of the outputs for groups that finished early
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int rb = r0 + 16 * mt + crow;
+        if (rb < a.B) {
+            if (a.hN) a.hN[(long long)rb * H + u0 + cunit] = h_reg[mt];
+            if (a.cN) a.cN[(long long)rb * H + u0 + cunit] = c_reg[mt];
+            for (int t = Tg; t < a.T; ++t) a.hs[((long long)t * a.B + rb) * H + u0 + cunit] = 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward sweep
+// ---------------------------------------------------------------------------------------------
+struct LstmBwdArgs {
+    int T, B, H, G, NW;
+    const float* whh;       // [4H][H]
+    const float* gates;     // [T][B][4H] saved post-activation gates
+    const float* cs;        // [T][B][H]
+    const float* c0;        // [B][H] or null
+    const int* lens;        // [B] or null
+    const float* dhs;       // [T][B][H] or null
+    const float* dhN; const float* dcN;   // [B][H] or null
+    float* dgates;          // [T][B][4H] (may alias gates)
+    float* dh0; float* dc0; // [B][H] or null
+    float* gxch;            // exchange [2][G][4][NW][MT][256]
+    unsigned* sync;
+    int need_dh0;           // run the recurrent product of the last step too
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float part[4][MT][16 * 20];
+    __shared__ __attribute__((aligned(16))) float stage[4][MT][256];
+    __shared__ int s_ok;
+
+    const int g = blockIdx.x % a.G, j = blockIdx.x / a.G;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int H = a.H, H4 = 4 * a.H;
+    const int njb = H >> 4;                 // 16-row k blocks per gate (<= 32)
+    const int u0 = 16 * j;
+    const int r0 = g * 16 * MT;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int crow = tid >> 4, cunit = tid & 15;
+
+    // wave w: rows [w*H, (w+1)*H) of W_hh (gate w), columns u0..u0+15
+    f32x4 wreg[32];
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (jj < njb) {
+            const float* p = a.whh + (long long)(w * H + 16 * jj + 4 * fq) * H + u0 + fr;
+            t.x = p[0]; t.y = p[H]; t.z = p[2 * H]; t.w = p[3 * H];
+        }
+        wreg[jj] = t;
+    }
+
+    unsigned* ctr = a.sync + 32 * g;
+    unsigned* tmo = a.sync + 32 * a.G;
+    const unsigned blk_bytes = 256 * 4;
+    const long long x_par = (long long)a.G * 4 * a.NW * MT * 256;
+    __amdgpu_buffer_rsrc_t rs = make_rsrc(a.gxch, (unsigned)(2 * x_par * 4));
+
+    float dh_rec[MT], dc_next[MT];
+    int len_r[MT];
+    int Tg = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int rb = r0 + 16 * mt + crow;
+        dh_rec[mt] = 0.f; dc_next[mt] = 0.f;
+        len_r[mt] = (rb < a.B) ? (a.lens ? min(a.lens[rb], a.T) : a.T) : 0;
+    }
+    if (a.lens) {
+        for (int r = 0; r < 16 * MT; ++r) {
+            const int rb = r0 + r;
+            if (rb < a.B) Tg = max(Tg, min(a.lens[rb], a.T));
+        }
+    } else {
+        Tg = a.T;
+    }
+
+    // rows that never ran: their dgates are zero for t in [Tg, T)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int rb = r0 + 16 * mt + crow;
+        if (rb < a.B)
+            for (int t = Tg; t < a.T; ++t) {
+                float* pd = a.dgates + ((long long)t * a.B + rb) * H4 + u0 + cunit;
+                pd[0] = 0.f; pd[H] = 0.f; pd[2 * H] = 0.f; pd[3 * H] = 0.f;
+            }
+    }
+
+    int s = 0;   // published steps so far
+    for (int t = Tg - 1; t >= 0; --t, ++s) {
+        const int par = s & 1;
+        // (a) cell backward for this thread's (row, unit)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rb = r0 + 16 * mt + crow;
+            float dp[4] = {0.f, 0.f, 0.f, 0.f};
+            if (rb < a.B) {
+                const long long o = ((long long)t * a.B + rb);
+                if (t < len_r[mt]) {
+                    const float* pg = a.gates + o * H4 + u0 + cunit;
+                    const float ig = pg[0], fg = pg[H], gg = pg[2 * H], og = pg[3 * H];
+                    const float ct = a.cs[o * H + u0 + cunit];
+                    float cp;
+                    if (t > 0) cp = a.cs[(o - a.B) * H + u0 + cunit];
+                    else cp = a.c0 ? a.c0[(long long)rb * H + u0 + cunit] : 0.f;
+                    float dh = dh_rec[mt];
+                    float dc = dc_next[mt];
+                    if (a.dhs) dh += a.dhs[o * H + u0 + cunit];
+                    if (t == len_r[mt] - 1) {
+                        if (a.dhN) dh += a.dhN[(long long)rb * H + u0 + cunit];
+                        if (a.dcN) dc += a.dcN[(long long)rb * H + u0 + cunit];
+                    }
+                    const float tc = tanhf_(ct);
+                    dc += dh * og * (1.f - tc * tc);
+                    dp[0] = dc * gg * ig * (1.f - ig);
+                    dp[1] = dc * cp * fg * (1.f - fg);
+                    dp[2] = dc * ig * (1.f - gg * gg);
+                    dp[3] = dh * tc * og * (1.f - og);
+                    dc_next[mt] = dc * fg;
+                }
+                float* pd = a.dgates + o * H4 + u0 + cunit;
+                pd[0] = dp[0]; pd[H] = dp[1]; pd[2 * H] = dp[2]; pd[3 * H] = dp[3];
+            }
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) stage[gt][mt][crow * 16 + cunit] = dp[gt];
+        }
+        if (t == 0 && !a.need_dh0) break;
+        __syncthreads();
+        // (b) publish dgates_t: wave w writes the blocks of gate w
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&stage[w][mt][4 * lane]);
+            const long long blk = ((((long long)par * a.G + g) * 4 + w) * a.NW + j) * MT + mt;
+            st16_sc1(rs, (unsigned)(blk * blk_bytes + lane * 16), v);
+        }
+        drain_vmem();
+        __syncthreads();
+        if (tid == 0) {
+            add_flag(ctr, 1u);
+            s_ok = wait_ge(ctr, (unsigned)(a.NW * (s + 1)), tmo) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_ok) break;
+        // (c) dh_rec[:, u0..u0+15] = dgates_t[:, gate w rows] * W_hh[gate w rows, u0..u0+15], K split over waves
+        f32x4 acc[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = acc[mt][0]; }
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc) {
+            f32x4 af[8][MT];
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int jj = jc * 8 + j8;
+                    af[j8][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (jj < njb) {
+                        const long long blk = ((((long long)par * a.G + g) * 4 + w) * a.NW + jj) * MT + mt;
+                        af[j8][mt] = ld16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + fq * 4) * 4));
+                    }
+                }
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8) {
+                const int jj = jc * 8 + j8;
+                if (jj < njb) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][j8 & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j8][mt][i], wreg[jj][i], acc[mt][j8 & 1], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[w][mt][(4 * fq + i) * 20 + fr] = acc[mt][0][i] + acc[mt][1][i];
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int o = crow * 20 + cunit;
+            dh_rec[mt] = (part[0][mt][o] + part[1][mt][o]) + (part[2][mt][o] + part[3][mt][o]);
+        }
+        // the next iteration's barrier after (a) orders these LDS reads before part[] is rewritten
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int rb = r0 + 16 * mt + crow;
+        if (rb < a.B) {
+            if (a.dh0) a.dh0[(long long)rb * H + u0 + cunit] = dh_rec[mt];
+            if (a.dc0) a.dc0[(long long)rb * H + u0 + cunit] = dc_next[mt];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int pick_mt(int B, int NW, int* G) {
+    for (int mt = 1; mt <= 4; mt *= 2) {
+        const int g = (B + 16 * mt - 1) / (16 * mt);
+        if ((long long)g * NW <= 256) { *G = g; return mt; }
+    }
+    return 0;
+}
+
+static bool bad_h(int H) { return H < 64 || H > 512 || (H & 63) != 0; }
+
+extern "C" int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out) {
+    if (B <= 0 || bad_h(H)) { a4nt_set_error("a4nt_lstm: H must be a multiple of 64 in [64,512], got H=%d B=%d", H, B); return A4NT_ERR_ARG; }
+    int G = 0;
+    const int mt = pick_mt(B, H / 16, &G);
+    if (!mt) { a4nt_set_error("a4nt_lstm: batch %d too large for one sweep at H=%d (max %d rows)", B, H, 64 * (256 / (H / 16))); return A4NT_ERR_ARG; }
+    *mt_out = mt; *groups_out = G;
+    return A4NT_OK;
+}
+
+// floats needed for the exchange buffer and unsigned words for the sync block
+extern "C" long long a4nt_lstm_xch_floats(int B, int H, int backward) {
+    int mt, G;
+    if (a4nt_lstm_geometry(B, H, &mt, &G) != A4NT_OK) return -1;
+    const long long per = (long long)G * (H / 16) * mt * 256;
+    return 2 * per * (backward ? 4 : 1);
+}
+extern "C" int a4nt_lstm_sync_words(int B, int H) {
+    int mt, G;
+    if (a4nt_lstm_geometry(B, H, &mt, &G) != A4NT_OK) return -1;
+    return 32 * G + 32;
+}
+
+static bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+extern "C" int a4nt_lstm_seq_fwd(int T, int B, int H, const float* gx, const float* gc, const float* whh, const float* h0,
+                                 const float* c0, const int* lens, float* hs, float* gates, float* cs, float* hN,
+                                 float* cN, float* xch, unsigned* sync, void* stream) {
+    int mt, G;
+    int rc = a4nt_lstm_geometry(B, H, &mt, &G);
+    if (rc != A4NT_OK) return rc;
+    if (T <= 0 || !gx || !whh || !hs || !xch || !sync || misaligned(whh) || misaligned(xch)) {
+        a4nt_set_error("a4nt_lstm_seq_fwd: bad arguments (T=%d, null or misaligned pointer)", T);
+        return A4NT_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sync, 0, (size_t)(32 * G + 32) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_fwd memset");
+    LstmFwdArgs a;
+    a.T = T; a.B = B; a.H = H; a.G = G; a.NW = H / 16;
+    a.gx = gx; a.whh = whh; a.h0 = h0; a.c0 = c0; a.lens = lens;
+    a.cg = gc; a.ptab = nullptr; a.tok = nullptr; a.val = nullptr;
+    a.hs = hs; a.gates = gates; a.cs = cs; a.hN = hN; a.cN = cN; a.hx = xch; a.sync = sync; a.mode = 0; a.step0 = 0;
+    dim3 grid(G * a.NW), block(256);
+    if (mt == 1) hipLaunchKernelGGL(lstm_fwd_kernel<1>, grid, block, 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL(lstm_fwd_kernel<2>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(lstm_fwd_kernel<4>, grid, block, 0, s, a);
+    return a4nt_check_launch("lstm_seq_fwd");
+}
+
+extern "C" int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const float* ptab, const long long* tok,
+                                  const float* val, const float* whh, const float* c_prev, float* h_out,
+                                  float* gates_out, float* c_out, float* xch, void* stream) {
+    int mt, G;
+    int rc = a4nt_lstm_geometry(B, H, &mt, &G);
+    if (rc != A4NT_OK) return rc;
+    if (!cg || !ptab || !tok || !val || !whh || !h_out || !xch || misaligned(whh) || misaligned(xch)) {
+        a4nt_set_error("a4nt_lstm_dec_step: null or misaligned pointer");
+        return A4NT_ERR_ARG;
+    }
+    LstmFwdArgs a;
+    a.T = 1; a.B = B; a.H = H; a.G = G; a.NW = H / 16;
+    a.gx = nullptr; a.whh = whh; a.h0 = nullptr; a.c0 = c_prev; a.lens = nullptr;
+    a.cg = cg; a.ptab = ptab; a.tok = tok; a.val = val;
+    a.hs = h_out; a.gates = gates_out; a.cs = c_out; a.hN = nullptr; a.cN = nullptr; a.hx = xch; a.sync = nullptr;
+    a.mode = 1; a.step0 = step;
+    dim3 grid(G * a.NW), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (mt == 1) hipLaunchKernelGGL(lstm_fwd_kernel<1>, grid, block, 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL(lstm_fwd_kernel<2>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(lstm_fwd_kernel<4>, grid, block, 0, s, a);
+    return a4nt_check_launch("lstm_dec_step");
+}
+
+extern "C" int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const float* gates, const float* cs,
+                                 const float* c0, const int* lens, const float* dhs, const float* dhN,
+                                 const float* dcN, float* dgates, float* dh0, float* dc0, float* xch, unsigned* sync,
+                                 void* stream) {
+    int mt, G;
+    int rc = a4nt_lstm_geometry(B, H, &mt, &G);
+    if (rc != A4NT_OK) return rc;
+    if (T <= 0 || !whh || !gates || !cs || !dgates || !xch || !sync || misaligned(xch)) {
+        a4nt_set_error("a4nt_lstm_seq_bwd: bad arguments (T=%d, null or misaligned pointer)", T);
+        return A4NT_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sync, 0, (size_t)(32 * G + 32) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_bwd memset");
+    LstmBwdArgs a;
+    a.T = T; a.B = B; a.H = H; a.G = G; a.NW = H / 16;
+    a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens; a.dhs = dhs; a.dhN = dhN; a.dcN = dcN;
+    a.dgates = dgates; a.dh0 = dh0; a.dc0 = dc0; a.gxch = xch; a.sync = sync;
+    a.need_dh0 = (dh0 != nullptr) ? 1 : 0;
+    dim3 grid(G * a.NW), block(256);
+    if (mt == 1) hipLaunchKernelGGL(lstm_bwd_kernel<1>, grid, block, 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL(lstm_bwd_kernel<2>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(lstm_bwd_kernel<4>, grid, block, 0, s, a);
+    return a4nt_check_launch("lstm_seq_bwd");
+}

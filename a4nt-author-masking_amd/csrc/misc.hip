@@ -1,0 +1,184 @@
+// Small HBM-bound helpers of the hot path: embedding gather / scatter-add (token ids and
+// straight-through sample values), column sums for bias gradients, split-K slab reduction, the
+// element-wise LSTM cell backward used by the free-running decoder's reverse loop, and the
+// leaky-relu + max-over-time epilogue of the CharCNN classifier.
+#include "common.h"
+
+// out[n][:] = (scale ? scale[n] : 1) * W[ids[n]][:]
+__global__ void embed_fwd_kernel(long long N, int E, const long long* ids, const float* scale, const float* W,
+                                 float* out, int ldo) {
+    const long long total = N * E;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / E; const int e = (int)(i - n * E);
+        const float s = scale ? scale[n] : 1.f;
+        out[n * ldo + e] = s * W[ids[n] * (long long)E + e];
+    }
+}
+extern "C" int a4nt_embed_fwd(long long N, int E, int V, const long long* ids, const float* scale, const float* W,
+                              float* out, int ldo, void* stream) {
+    if (N <= 0) return A4NT_OK;
+    if (E <= 0 || V <= 0 || !ids || !W || !out) { a4nt_set_error("a4nt_embed_fwd: bad arguments"); return A4NT_ERR_ARG; }
+    const long long total = N * E;
+    const int grid = (int)min((long long)2048, (total + 255) / 256);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, E, ids, scale, W, out, ldo);
+    return a4nt_check_launch("embed_fwd");
+}
+
+// dW[ids[n]][:] += (scale ? scale[n] : 1) * dout[n][:]   (rows with ids[n] == padding_idx skipped)
+__global__ void embed_bwd_kernel(long long N, int E, const long long* ids, const float* scale, const float* dout,
+                                 int ldd, float* dW, long long padding_idx) {
+    const long long total = N * E;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / E; const int e = (int)(i - n * E);
+        const long long id = ids[n];
+        if (id == padding_idx) continue;
+        const float s = scale ? scale[n] : 1.f;
+        if (s == 0.f) continue;
+        atomicAdd(&dW[id * (long long)E + e], s * dout[n * ldd + e]);
+    }
+}
+extern "C" int a4nt_embed_bwd(long long N, int E, int V, const long long* ids, const float* scale, const float* dout,
+                              int ldd, float* dW, long long padding_idx, void* stream) {
+    if (N <= 0) return A4NT_OK;
+    if (E <= 0 || V <= 0 || !ids || !dout || !dW) { a4nt_set_error("a4nt_embed_bwd: bad arguments"); return A4NT_ERR_ARG; }
+    const long long total = N * E;
+    const int grid = (int)min((long long)2048, (total + 255) / 256);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, E, ids, scale, dout, ldd, dW,
+                       padding_idx);
+    return a4nt_check_launch("embed_bwd");
+}
+
+// out[n] (+)= sum_m A[m][n]
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* A, int lda, float* out, int rows_per) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+    float s = 0.f;
+    if (c < N)
+        for (int m = m0 + w; m < m1; m += 4) s += A[(long long)m * lda + c];
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < N) atomicAdd(&out[c], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+extern "C" int a4nt_colsum(int M, int N, const float* A, int lda, float* out, int accumulate, void* stream) {
+    if (N <= 0) return A4NT_OK;
+    if (!A || !out || M < 0) { a4nt_set_error("a4nt_colsum: bad arguments"); return A4NT_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * 4, s) != hipSuccess) return a4nt_check_launch("colsum memset");
+    if (M == 0) return A4NT_OK;
+    const int cb = (N + 63) / 64;
+    int chunks = max(1, min((M + 63) / 64, 2048 / cb));
+    const int rows_per = (M + chunks - 1) / chunks;
+    chunks = (M + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cb, chunks), dim3(256), 0, s, M, N, A, lda, out, rows_per);
+    return a4nt_check_launch("colsum");
+}
+
+// out[r][c] = sum_s slabs[s*stride + r*lds + c0 + c] (+ add[r][c]),  r < R, c < C
+__global__ void slab_reduce_kernel(int S, long long stride, int R, int C, const float* slabs, int lds, int c0,
+                                   const float* add, int lda, float* out, int ldo) {
+    const long long total = (long long)R * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / C), c = (int)(i - (long long)r * C);
+        float v = add ? add[(long long)r * lda + c] : 0.f;
+        for (int s = 0; s < S; ++s) v += slabs[s * stride + (long long)r * lds + c0 + c];
+        out[(long long)r * ldo + c] = v;
+    }
+}
+extern "C" int a4nt_slab_reduce(int S, long long stride, int R, int C, const float* slabs, int lds, int c0,
+                                const float* add, int lda, float* out, int ldo, void* stream) {
+    if (R <= 0 || C <= 0) return A4NT_OK;
+    if (S < 1 || !slabs || !out) { a4nt_set_error("a4nt_slab_reduce: bad arguments"); return A4NT_ERR_ARG; }
+    const long long total = (long long)R * C;
+    const int grid = (int)min((long long)1024, (total + 255) / 256);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, S, stride, R, C, slabs, lds, c0,
+                       add, lda, out, ldo);
+    return a4nt_check_launch("slab_reduce");
+}
+
+// Element-wise LSTM cell backward of one decoder step:
+//   dh = dh_a + dh_b ; dc = dc_io + dh*o*(1-tanh(c)^2) ; dgates (pre-activation) ; dc_io = dc*f
+__global__ void lstm_cell_bwd_kernel(int B, int H, const float* gates, const float* c_t, const float* c_prev,
+                                     const float* dh_a, const float* dh_b, float* dc_io, float* dgates) {
+    const long long total = (long long)B * H;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / H), u = (int)(i - (long long)b * H);
+        const float* pg = gates + (long long)b * 4 * H + u;
+        const float ig = pg[0], fg = pg[H], gg = pg[2 * H], og = pg[3 * H];
+        float dh = 0.f;
+        if (dh_a) dh += dh_a[i];
+        if (dh_b) dh += dh_b[i];
+        const float tc = tanhf_(c_t[i]);
+        const float cp = c_prev ? c_prev[i] : 0.f;
+        const float dc = dc_io[i] + dh * og * (1.f - tc * tc);
+        float* pd = dgates + (long long)b * 4 * H + u;
+        pd[0] = dc * gg * ig * (1.f - ig);
+        pd[H] = dc * cp * fg * (1.f - fg);
+        pd[2 * H] = dc * ig * (1.f - gg * gg);
+        pd[3 * H] = dh * tc * og * (1.f - og);
+        dc_io[i] = dc * fg;
+    }
+}
+extern "C" int a4nt_lstm_cell_bwd(int B, int H, const float* gates, const float* c_t, const float* c_prev,
+                                  const float* dh_a, const float* dh_b, float* dc_io, float* dgates, void* stream) {
+    if (B <= 0 || H <= 0) return A4NT_OK;
+    if (!gates || !c_t || !dc_io || !dgates) { a4nt_set_error("a4nt_lstm_cell_bwd: bad arguments"); return A4NT_ERR_ARG; }
+    const long long total = (long long)B * H;
+    const int grid = (int)min((long long)1024, (total + 255) / 256);
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, H, gates, c_t, c_prev, dh_a,
+                       dh_b, dc_io, dgates);
+    return a4nt_check_launch("lstm_cell_bwd");
+}
+
+// CharCNN epilogue.  pre: [Tout][B][F] conv pre-activations (time major, bias included).
+// feat[b][f] = max over the padded time axis of leaky_relu(pre), where `pad` zero positions take
+// part in the max iff pad > 0 (reference char_cnn.py:84-92 pads branches to a common length with
+// zeros before the global max-pool).  argmax[b][f] = winning time step, or -1 when a zero pad won.
+__global__ void lrelu_maxtime_kernel(int Tout, int B, int F, const float* pre, int ldp, float slope, int pad,
+                                     float* feat, int ldf, int* argmax) {
+    const long long total = (long long)B * F;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / F), f = (int)(i - (long long)b * F);
+        float best = pad > 0 ? 0.f : -INFINITY; int bi = -1;
+        for (int t = 0; t < Tout; ++t) {
+            float v = pre[((long long)t * B + b) * ldp + f];
+            v = v > 0.f ? v : v * slope;
+            if (v > best) { best = v; bi = t; }
+        }
+        feat[(long long)b * ldf + f] = best;
+        argmax[i] = bi;
+    }
+}
+extern "C" int a4nt_lrelu_maxtime(int Tout, int B, int F, const float* pre, int ldp, float slope, int pad, float* feat,
+                                  int ldf, int* argmax, void* stream) {
+    if (B <= 0 || F <= 0) return A4NT_OK;
+    if (Tout <= 0 || !pre || !feat || !argmax) { a4nt_set_error("a4nt_lrelu_maxtime: bad arguments"); return A4NT_ERR_ARG; }
+    const long long total = (long long)B * F;
+    const int grid = (int)min((long long)1024, (total + 255) / 256);
+    hipLaunchKernelGGL(lrelu_maxtime_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Tout, B, F, pre, ldp, slope,
+                       pad, feat, ldf, argmax);
+    return a4nt_check_launch("lrelu_maxtime");
+}
+// dpre[t][b][f] = (t == argmax[b][f]) ? dfeat[b][f] * lrelu'(pre) : 0     (in place over pre)
+__global__ void lrelu_maxtime_bwd_kernel(int Tout, int B, int F, float* pre, int ldp, float slope, const float* dfeat,
+                                         int ldf, const int* argmax) {
+    const long long total = (long long)Tout * B * F;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F); const long long tb = i / F; const int b = (int)(tb % B); const int t = (int)(tb / B);
+        float* p = pre + tb * ldp + f;
+        float g = 0.f;
+        if (argmax[(long long)b * F + f] == t) g = dfeat[(long long)b * ldf + f] * (*p > 0.f ? 1.f : slope);
+        *p = g;
+    }
+}
+extern "C" int a4nt_lrelu_maxtime_bwd(int Tout, int B, int F, float* pre, int ldp, float slope, const float* dfeat,
+                                      int ldf, const int* argmax, void* stream) {
+    if (B <= 0 || F <= 0 || Tout <= 0) return A4NT_OK;
+    if (!pre || !dfeat || !argmax) { a4nt_set_error("a4nt_lrelu_maxtime_bwd: bad arguments"); return A4NT_ERR_ARG; }
+    const long long total = (long long)Tout * B * F;
+    const int grid = (int)min((long long)2048, (total + 255) / 256);
+    hipLaunchKernelGGL(lrelu_maxtime_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Tout, B, F, pre, ldp, slope,
+                       dfeat, ldf, argmax);
+    return a4nt_check_launch("lrelu_maxtime_bwd");
+}

@@ -1,0 +1,209 @@
+// Row kernels over the vocabulary axis (HBM/L2-bound; one 256-thread workgroup per row):
+//   * gumbel_fwd : scale -> log_softmax -> + Gumbel noise -> /tau -> softmax stats -> argmax,
+//                  straight-through one-hot value, done / length bookkeeping of the free-running
+//                  generator (reference models/char_translator.py:10-28, 375-392), greedy argmax
+//   * gumbel_bwd : dlogits = (scale/tau) * p * (ds - <p, ds>)   (softmax + log_softmax backward;
+//                  the log_softmax term vanishes because the softmax-backward rows sum to zero)
+//   * nll_rows   : log-softmax + NLL of the teacher-forced / reconstruction pass, leaves
+//                  (softmax - onehot) * gscale in place of the logits (fused CE backward)
+#include "common.h"
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// Philox4x32-10 (Salmon et al.), counter = (elem/4, row, step, 0), key = seed
+__device__ __forceinline__ void philox4(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                        unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float uniform_at(unsigned long long seed, unsigned step, unsigned row, unsigned v) {
+    unsigned o[4];
+    philox4(v >> 2, row, step, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+    return (float)(o[v & 3] >> 8) * (1.0f / 16777216.0f);      // [0,1) with 24 bits
+}
+
+struct GumbelFwdArgs {
+    const float* logits; int ldl; int V;
+    const float* U; int ldu;           // injected uniforms or null (then Philox(seed, step, row, v))
+    unsigned long long seed; unsigned step;
+    float scale, tau;
+    int greedy;                        // 1: argmax of the raw logits, nothing else
+    float* y; int ldy;                 // tempered noisy log-probs (saved for backward) or null
+    float* stats;                      // [B][2] = (max y, sum exp(y - max))
+    long long* tok;                    // [B] argmax
+    float* val_in;                     // [B] value fed to the next decoder step (un-masked)
+    float* val_out;                    // [B] value handed to consumers (0 once the row was done)
+    int* gen_lens; unsigned char* done; long long end_c;
+    float* dense; int ldd; int hard;   // optional dense sample row (generic path)
+};
+
+__global__ __launch_bounds__(256) void gumbel_fwd_kernel(GumbelFwdArgs a) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* x = a.logits + (long long)b * a.ldl;
+    const int V = a.V;
+    float best = -INFINITY; int besti = 0x7fffffff;
+
+    if (a.greedy) {
+        for (int v = tid; v < V; v += 256) { const float f = x[v]; if (f > best) { best = f; besti = v; } }
+    } else {
+        float m1 = -INFINITY;
+        for (int v = tid; v < V; v += 256) m1 = fmaxf(m1, x[v] * a.scale);
+        m1 = block_max(m1, red);
+        float s1 = 0.f;
+        for (int v = tid; v < V; v += 256) s1 += expf(x[v] * a.scale - m1);
+        s1 = block_sum(s1, red);
+        const float lse = logf(s1);
+        float* y = a.y + (long long)b * a.ldy;
+        for (int v = tid; v < V; v += 256) {
+            const float u = a.U ? a.U[(long long)b * a.ldu + v] : uniform_at(a.seed, a.step, (unsigned)b, (unsigned)v);
+            const float gn = -logf(-logf(u + 1e-20f) + 1e-20f);
+            const float lsm = (x[v] * a.scale - m1) - lse;
+            const float yy = (lsm + gn) / a.tau;
+            y[v] = yy;
+            if (yy > best) { best = yy; besti = v; }
+        }
+    }
+    // block argmax, lowest index on ties
+    {
+        const float bm = block_max(best, red);
+        int cand = (best == bm) ? besti : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+        __syncthreads();
+        if ((tid & 63) == 0) redi[tid >> 6] = cand;
+        __syncthreads();
+        besti = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+        best = bm;
+    }
+    float hot = 1.0f, s2 = 1.0f;
+    if (!a.greedy) {
+        const float* y = a.y + (long long)b * a.ldy;
+        float s = 0.f;
+        for (int v = tid; v < V; v += 256) s += expf(y[v] - best);
+        s2 = block_sum(s, red);
+        const float p_hot = 1.0f / s2;                 // exp(0) / sum
+        hot = a.hard ? ((1.0f - p_hot) + p_hot) : p_hot;   // (one_hot - ysft.data) + ysft at the hot index
+    }
+    const bool prev_done = a.done ? (a.done[b] != 0) : false;
+    if (a.dense) {
+        float* d = a.dense + (long long)b * a.ldd;
+        if (a.hard) {
+            for (int v = tid; v < V; v += 256) d[v] = (v == besti) ? hot : 0.f;
+        } else {
+            const float* y = a.y + (long long)b * a.ldy;
+            for (int v = tid; v < V; v += 256) d[v] = expf(y[v] - best) / s2;
+        }
+    }
+    if (tid == 0) {
+        if (a.stats) { a.stats[2 * b] = best; a.stats[2 * b + 1] = s2; }
+        a.tok[b] = besti;
+        if (a.val_in) a.val_in[b] = hot;
+        if (a.val_out) a.val_out[b] = prev_done ? 0.f : hot;
+        if (a.gen_lens) a.gen_lens[b] += prev_done ? 0 : 1;
+        if (a.done) a.done[b] = (prev_done || (long long)besti == a.end_c) ? 1 : 0;
+    }
+}
+
+extern "C" int a4nt_gumbel_fwd(int B, int V, const float* logits, int ldl, const float* U, int ldu,
+                               unsigned long long seed, unsigned step, float scale, float tau, int hard, int greedy,
+                               float* y, int ldy, float* stats, long long* tok, float* val_in, float* val_out,
+                               int* gen_lens, unsigned char* done, long long end_c, float* dense, int ldd,
+                               void* stream) {
+    if (B <= 0) return A4NT_OK;
+    if (V <= 0 || !logits || !tok || (!greedy && (!y || tau <= 0.f))) {
+        a4nt_set_error("a4nt_gumbel_fwd: bad arguments (V=%d tau=%g)", V, (double)tau);
+        return A4NT_ERR_ARG;
+    }
+    GumbelFwdArgs a;
+    a.logits = logits; a.ldl = ldl; a.V = V; a.U = U; a.ldu = ldu; a.seed = seed; a.step = step; a.scale = scale;
+    a.tau = tau; a.greedy = greedy; a.y = y; a.ldy = ldy; a.stats = stats; a.tok = tok; a.val_in = val_in;
+    a.val_out = val_out; a.gen_lens = gen_lens; a.done = done; a.end_c = end_c; a.dense = dense; a.ldd = ldd;
+    a.hard = hard;
+    hipLaunchKernelGGL(gumbel_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    return a4nt_check_launch("gumbel_fwd");
+}
+
+// ds (in) -> dlogits (out, in place).  p = exp(y - stats[0]) / stats[1].
+__global__ __launch_bounds__(256) void gumbel_bwd_kernel(int V, float* ds, int ldd, const float* y, int ldy,
+                                                         const float* stats, float coef) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* d = ds + (long long)b * ldd;
+    const float* yy = y + (long long)b * ldy;
+    const float m2 = stats[2 * b], inv = 1.0f / stats[2 * b + 1];
+    float dot = 0.f;
+    for (int v = tid; v < V; v += 256) dot += (expf(yy[v] - m2) * inv) * d[v];
+    dot = block_sum(dot, red);
+    for (int v = tid; v < V; v += 256) d[v] = coef * (expf(yy[v] - m2) * inv) * (d[v] - dot);
+}
+
+extern "C" int a4nt_gumbel_bwd(int B, int V, float* ds, int ldd, const float* y, int ldy, const float* stats,
+                               float coef, void* stream) {
+    if (B <= 0) return A4NT_OK;
+    if (V <= 0 || !ds || !y || !stats) { a4nt_set_error("a4nt_gumbel_bwd: bad arguments"); return A4NT_ERR_ARG; }
+    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, V, ds, ldd, y, ldy, stats, coef);
+    return a4nt_check_launch("gumbel_bwd");
+}
+
+// Fused log-softmax + NLL + backward seed.  target < 0: row ignored (loss 0, gradient 0).
+__global__ __launch_bounds__(256) void nll_rows_kernel(int V, float* logits, int ld, const long long* target,
+                                                       float gscale, float* loss_rows, int write_grad) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    float* x = logits + (long long)r * ld;
+    const long long tg = target[r];
+    if (tg < 0) {
+        if (write_grad) for (int v = tid; v < V; v += 256) x[v] = 0.f;
+        if (tid == 0) loss_rows[r] = 0.f;
+        return;
+    }
+    float m = -INFINITY;
+    for (int v = tid; v < V; v += 256) m = fmaxf(m, x[v]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int v = tid; v < V; v += 256) s += expf(x[v] - m);
+    s = block_sum(s, red);
+    const float lse = m + logf(s);
+    if (tid == 0) loss_rows[r] = lse - x[tg];
+    if (write_grad) {
+        __syncthreads();
+        const float inv = 1.0f / s;
+        for (int v = tid; v < V; v += 256) {
+            const float p = expf(x[v] - m) * inv;
+            x[v] = (p - ((long long)v == tg ? 1.f : 0.f)) * gscale;
+        }
+    }
+}
+
+extern "C" int a4nt_nll_rows(int N, int V, float* logits, int ld, const long long* target, float gscale,
+                             float* loss_rows, int write_grad, void* stream) {
+    if (N <= 0) return A4NT_OK;
+    if (V <= 0 || !logits || !target || !loss_rows) { a4nt_set_error("a4nt_nll_rows: bad arguments"); return A4NT_ERR_ARG; }
+    hipLaunchKernelGGL(nll_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, V, logits, ld, target, gscale,
+                       loss_rows, write_grad);
+    return a4nt_check_launch("nll_rows");
+}

@@ -1,0 +1,303 @@
+"""Free-running generator loop of CharTranslator.forward_advers_gen as ONE fused autograd operator,
+and the compact representation of its straight-through samples.
+
+Reference: models/char_translator.py:347-401 (loop), :10-28 (Gumbel-softmax).
+
+What is fused / restructured for MI355X (numerically equivalent within fp32 rounding):
+  * the decoder input of every step is [ctxt, emb]; ctxt is constant, so ctxt*W_ic^T (+ both biases)
+    is computed once (cg) and emb*W_ie^T is tabulated per token once per call (ptab = E*W_ie^T), so
+    a step is: gather + recurrent MFMA + fused cell update (a4nt_lstm_dec_step);
+  * with gumbel_hard the sample is one_hot*val (val = (1-p)+p at the arg-max), so samples travel
+    as (token, value) pairs (SoftSamples) and `samp.mm(embedding)` in any consumer is a scaled gather;
+  * the backward never materialises d(sample): consumers register their d(embedding) [T,B,E] and
+    embedding matrix with the operator, whose reverse loop contracts them over the vocabulary
+    inside the per-step Gumbel-softmax backward (a4nt_sgemm + a4nt_gumbel_bwd);
+  * no host sync per step: `done` / `gen_lens` live on the device; the host looks at them every
+    CHECK_EVERY steps and once at the end (the reference syncs every step, :393).
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import gemm, gemm_auto, slab_reduce, colsum, embed_fwd, embed_bwd
+
+CHECK_EVERY = 16
+
+
+class _GenHandle(object):
+    """Side channel between the generation operator and the consumers of its samples."""
+
+    def __init__(self):
+        self.contribs = []        # (demb [n,B,E], W [V,E]) registered by consumers' backward
+        self.dense_grads = []     # dense d(sample) [n,B,V] (API path that materialised the samples)
+
+
+class SoftSamples(object):
+    """Straight-through one-hot samples as (tok [T,B] int64, val [T,B] fp32).
+
+    Row t, column b stands for the dense row  val[t,b] * one_hot(tok[t,b])  of the reference's
+    [T,B,V] sample tensor (val is 0 for rows generated after the sequence finished,
+    char_translator.py:384).  `origin` = (handle, t_offset, perm): row t >= t_offset, column b came
+    from generator step t - t_offset, generator batch column perm[b].
+    """
+
+    def __init__(self, tok, val, vocab, origin=None):
+        self.tok, self.val, self.vocab, self.origin = tok, val, vocab, origin
+
+    @property
+    def shape(self):
+        return (self.tok.shape[0], self.tok.shape[1], self.vocab)
+
+    def size(self, i):
+        return self.shape[i]
+
+    def detach(self):
+        return SoftSamples(self.tok, self.val.detach(), self.vocab, None)
+
+    def index_select_batch(self, idx):
+        """samples.index_select(1, idx) of the reference (train_adversarial_translator.py:143)."""
+        origin = None
+        if self.origin is not None:
+            h, off, perm = self.origin
+            origin = (h, off, idx if perm is None else perm.index_select(0, idx))
+        return SoftSamples(self.tok.index_select(1, idx), self.val.index_select(1, idx), self.vocab, origin)
+
+    def prepend_token(self, token_id):
+        """torch.cat([one_hot(start), samples]) of the reference (train_adversarial_translator.py:158)."""
+        B = self.tok.shape[1]
+        t0 = torch.full((1, B), int(token_id), dtype=torch.int64, device=self.tok.device)
+        v0 = torch.ones((1, B), dtype=torch.float32, device=self.val.device)
+        origin = None
+        if self.origin is not None:
+            h, off, perm = self.origin
+            origin = (h, off + 1, perm)
+        return SoftSamples(torch.cat([t0, self.tok]), torch.cat([v0, self.val]), self.vocab, origin)
+
+    def to_dense(self):
+        return _DenseFromCompact.apply(self.val, self.tok, self.vocab, self.origin)
+
+
+def _register(origin, demb):
+    """demb: [T',B',E] gradient w.r.t. val*W[tok] in the (shifted, permuted) frame of a SoftSamples."""
+    handle, off, perm, W = origin
+    g = demb[off:]
+    if perm is not None:
+        full = torch.empty_like(g)
+        full.index_copy_(1, perm, g)
+        g = full
+    handle.contribs.append((g.contiguous(), W))
+
+
+class _SampleEmbed(Function):
+    """emb[t,b,:] = val[t,b] * W[tok[t,b],:]  ==  samples.view(T*B,V).mm(W) for one-hot samples
+    (char_translator.py:214,329,381; char_lstm.py:289; char_cnn.py:73)."""
+
+    @staticmethod
+    def forward(ctx, val, tok, W, origin):
+        ctx.save_for_backward(val, tok, W)
+        ctx.origin = origin
+        return embed_fwd(tok, W, val.contiguous())
+
+    @staticmethod
+    def backward(ctx, demb):
+        val, tok, W = ctx.saved_tensors
+        demb = demb.contiguous()
+        dW = None
+        if ctx.needs_input_grad[2]:
+            dW = torch.zeros_like(W)
+            embed_bwd(tok, demb, dW, val.contiguous(), -1)     # a dense mm has no padding_idx
+        if ctx.origin is not None and ctx.needs_input_grad[0]:
+            _register(ctx.origin + (W,), demb)
+        dval = torch.zeros_like(val) if ctx.needs_input_grad[0] else None
+        return dval, None, dW, None
+
+
+def sample_embed(samples, W):
+    return _SampleEmbed.apply(samples.val, samples.tok, W, samples.origin)
+
+
+class _DenseFromCompact(Function):
+    """Materialise the reference's dense [T,B,V] sample tensor (API compatibility path)."""
+
+    @staticmethod
+    def forward(ctx, val, tok, vocab, origin):
+        T, B = tok.shape
+        dense = torch.zeros((T, B, vocab), device=val.device, dtype=torch.float32)
+        dense.view(T * B, vocab).scatter_(1, tok.reshape(-1, 1), val.reshape(-1, 1))
+        ctx.origin = origin
+        return dense
+
+    @staticmethod
+    def backward(ctx, dd):
+        if ctx.origin is not None:
+            handle, off, perm = ctx.origin
+            g = dd[off:]
+            if perm is not None:
+                full = torch.empty_like(g)
+                full.index_copy_(1, perm, g)
+                g = full
+            handle.dense_grads.append(g.contiguous())
+        return torch.zeros(dd.shape[:2], device=dd.device), None, None, None
+
+
+class _GenDecode(Function):
+    @staticmethod
+    def forward(ctx, ctxt, tok0, emb_W, w_ih, w_hh, b_ih, b_hh, W_out, b_out, cfg, holder):
+        from . import _lib
+        lib = _lib.load()
+        dev = ctxt.device
+        B, Hc = ctxt.shape
+        H = w_hh.shape[1]
+        V, E = emb_W.shape
+        n_max = int(cfg['n_max'])
+        greedy = bool(cfg['greedy'])
+        need_grad = bool(cfg['need_grad']) and not greedy
+        noise = cfg.get('noise')          # list of [B,V] uniforms or None
+        w_ic = w_ih[:, :Hc]
+        w_ie = w_ih[:, Hc:].contiguous()
+        w_hh_c = w_hh.contiguous()
+        cg = gemm(ctxt.contiguous(), w_ic, transB=True, bias=(b_ih + b_hh))            # [B,4H]
+        ptab = gemm(emb_W, w_ie, transB=True)                                          # [V,4H]
+        xch, _, _ = ops._lstm_ws(dev, B, H, False)
+        xch.zero_()
+        hs_all = torch.zeros((n_max + 1, B, H), device=dev)
+        gates = torch.empty((n_max, B, 4 * H), device=dev)
+        cs = torch.empty((n_max, B, H), device=dev)
+        n_y = n_max if need_grad else 1
+        ybuf = None if greedy else torch.empty((n_y, B, V), device=dev)
+        stats = torch.empty((n_max, B, 2), device=dev)
+        tok = torch.zeros((n_max, B), dtype=torch.int64, device=dev)
+        val_in = torch.ones((n_max, B), device=dev)
+        val_out = torch.zeros((n_max, B), device=dev)
+        gen_lens = torch.zeros(B, dtype=torch.int32, device=dev)
+        done = torch.zeros(B, dtype=torch.uint8, device=dev)
+        logits = torch.empty((B, V), device=dev)
+        ones = torch.ones(B, device=dev)
+        tok0 = tok0.contiguous()
+        s = ops._s()
+        ran = 0
+        for t in range(n_max):
+            tk = tok0 if t == 0 else tok[t - 1]
+            vl = ones if t == 0 else val_in[t - 1]
+            cp = None if t == 0 else cs[t - 1]
+            _lib.check(lib.a4nt_lstm_dec_step(t, B, H, ops._p(cg), ops._p(ptab), ops._p(tk), ops._p(vl), ops._p(w_hh_c),
+                                              ops._p(cp), ops._p(hs_all[t + 1]), ops._p(gates[t]), ops._p(cs[t]),
+                                              ops._p(xch), s), 'a4nt_lstm_dec_step')
+            gemm(hs_all[t + 1], W_out, bias=b_out, out=logits)
+            U = None
+            if noise is not None and not greedy and t < len(noise):
+                U = noise[t].contiguous()      # injected uniforms (parity tests); Philox beyond the list
+                assert tuple(U.shape) == (B, V)
+            ops.gumbel_rows(logits, U, cfg.get('seed', 0), cfg.get('step0', 0) + t, cfg['scale'], cfg['tau'],
+                            cfg['hard'], greedy, None if greedy else ybuf[t if need_grad else 0], stats[t], tok[t],
+                            val_in[t], val_out[t], gen_lens, done, cfg['end_c'])
+            ran = t + 1
+            if cfg['end_c'] >= 0 and (ran % CHECK_EVERY == 0) and ran < n_max and bool(done.all()):
+                break
+        n_out = int(gen_lens.max().item())          # = steps the reference loop would have run
+        n_out = max(1, min(n_out, ran))
+        if noise is not None and not greedy:
+            # the reference stops drawing noise when its loop breaks: consume exactly n_out draws
+            assert n_out <= len(noise), 'injected noise list shorter than the generated length'
+            del noise[:n_out]
+        holder['handle'] = _GenHandle() if need_grad else None
+        holder['n_out'] = n_out
+        ctx.handle = holder['handle']
+        ctx.cfg = dict(cfg, noise=None)
+        ctx.n = n_out
+        if need_grad:
+            ctx.save_for_backward(ctxt, tok0, emb_W, w_ih, w_hh_c, W_out, hs_all, gates, cs, ybuf, stats, tok, val_in,
+                                  val_out)
+        tok_ret = tok[:n_out].clone()
+        ctx.mark_non_differentiable(tok_ret, gen_lens)
+        return val_out[:n_out].clone(), tok_ret, gen_lens
+
+    @staticmethod
+    def backward(ctx, _dval, _dtok, _dlens):
+        from . import _lib
+        lib = _lib.load()
+        (ctxt, tok0, emb_W, w_ih, w_hh, W_out, hs_all, gates, cs, ybuf, stats, tok, val_in, val_out) = ctx.saved_tensors
+        cfg, n, handle = ctx.cfg, ctx.n, ctx.handle
+        dev = ctxt.device
+        B, Hc = ctxt.shape
+        H = w_hh.shape[1]
+        V, E = emb_W.shape
+        s = ops._s()
+        # d(sample) from every consumer, contracted over its embedding matrix, time-batched
+        S = torch.empty((n, B, V), device=dev)
+        S2 = S.view(n * B, V)
+        first = True
+        for demb, W in handle.contribs:
+            gemm(demb[:n].reshape(n * B, -1), W, transB=True, out=S2, beta=0 if first else 1)
+            first = False
+        for dd in handle.dense_grads:
+            if first:
+                S.copy_(dd[:n])
+            else:
+                S.add_(dd[:n])
+            first = False
+        if first:
+            S.zero_()
+        handle.contribs, handle.dense_grads = [], []
+        w_ic = w_ih[:, :Hc]
+        w_ie = w_ih[:, Hc:].contiguous()
+        Wcat = torch.cat([w_hh, w_ie], dim=1).contiguous()             # [4H, H+E]
+        coef = float(cfg['scale']) / float(cfg['tau'])
+        dc = torch.zeros((B, H), device=dev)
+        dG = torch.empty((n, B, 4 * H), device=dev)
+        demb_all = torch.empty((n, B, E), device=dev)
+        dh_rec, demb_next = None, None
+        ks_v = ops._auto_ksplit(B, H, V)
+        ks_r = ops._auto_ksplit(B, H + E, 4 * H)
+        for t in range(n - 1, -1, -1):
+            if demb_next is not None:
+                gemm(demb_next, emb_W, transB=True, out=S[t], beta=1)
+            ops.gumbel_bwd_rows(S[t], ybuf[t], stats[t], coef)                      # S[t] := dlogits_t
+            if ks_v > 1:
+                dh = slab_reduce(gemm(S[t], W_out, transB=True, ksplit=ks_v), add=dh_rec)
+            else:
+                dh = gemm(S[t], W_out, transB=True)
+                if dh_rec is not None:
+                    dh = dh + dh_rec
+            _lib.check(lib.a4nt_lstm_cell_bwd(B, H, ops._p(gates[t]), ops._p(cs[t]), ops._p(cs[t - 1] if t > 0 else None),
+                                              ops._p(dh), None, ops._p(dc), ops._p(dG[t]), s), 'a4nt_lstm_cell_bwd')
+            if ks_r > 1:
+                slabs = gemm(dG[t], Wcat, ksplit=ks_r)
+                dh_rec = slab_reduce(slabs, 0, H)
+                demb_next = slab_reduce(slabs, H, E)
+            else:
+                both = gemm(dG[t], Wcat)
+                dh_rec, demb_next = both[:, :H].contiguous(), both[:, H:].contiguous()
+            demb_all[t].copy_(demb_next)
+        dG2 = dG.view(n * B, 4 * H)
+        d_W_out = gemm_auto(hs_all[1:n + 1].reshape(n * B, H), S2, transA=True)
+        d_b_out = colsum(S2)
+        d_w_hh = gemm_auto(dG2, hs_all[:n].reshape(n * B, H), transA=True)
+        # decoder inputs: step 0 = E[x0] (nn.Embedding, padding row 0 has no gradient);
+        # step t>0 = val_in[t-1]*E[tok[t-1]] (a dense mm in the reference: no padding semantics, and its
+        # weight gradient sees the .data-zeroed sample, i.e. val_out, char_translator.py:381-385)
+        tok_prev = torch.cat([tok0.view(1, B), tok[:n - 1]])
+        val_prev_fwd = torch.cat([torch.ones((1, B), device=dev), val_in[:n - 1]])
+        emb_in = embed_fwd(tok_prev, emb_W, val_prev_fwd.contiguous())
+        d_w_ie = gemm_auto(dG2, emb_in.view(n * B, E), transA=True)
+        sumG = colsum(dG.view(n, B * 4 * H)).view(B, 4 * H)
+        d_w_ic = gemm(sumG, ctxt, transA=True)
+        d_ctxt = gemm(sumG, w_ic)
+        d_b = colsum(dG2)
+        d_w_ih = torch.cat([d_w_ic, d_w_ie], dim=1)
+        d_emb = torch.zeros_like(emb_W)
+        embed_bwd(tok0, demb_all[0], d_emb, None, 0)
+        if n > 1:
+            embed_bwd(tok[:n - 1], demb_all[1:], d_emb, val_out[:n - 1].contiguous(), -1)
+        return d_ctxt, None, d_emb, d_w_ih, d_w_hh, d_b, d_b, d_W_out, d_b_out, None, None
+
+
+def gen_decode(ctxt, tok0, emb_W, w_ih, w_hh, b_ih, b_hh, W_out, b_out, cfg):
+    """Returns (SoftSamples or None, gen_lens [B] int32, tok [n,B] int64)."""
+    holder = {}
+    val_out, tok, gen_lens = _GenDecode.apply(ctxt, tok0, emb_W, w_ih, w_hh, b_ih, b_hh, W_out, b_out, cfg, holder)
+    samples = None
+    if not cfg['greedy']:
+        origin = (holder['handle'], 0, None) if holder['handle'] is not None else None
+        samples = SoftSamples(tok, val_out, emb_W.shape[0], origin)
+    return samples, gen_lens, tok

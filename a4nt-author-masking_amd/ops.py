@@ -1,0 +1,398 @@
+"""Host-side operators over the C-ABI kernels (include/a4nt_hip.h).
+
+Everything here allocates with torch, passes raw device pointers + the current HIP stream to
+liba4nt_hip.so and wires the results into torch.autograd.  There is no CPU / eager fallback: a
+tensor that is not a float32 CUDA tensor is an error.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check, A4NTError
+
+
+# ----------------------------------------------------------------------------------------------
+# plumbing
+# ----------------------------------------------------------------------------------------------
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, what):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise A4NTError('%s must be a float32 CUDA tensor (got %s on %s); the HIP path has no CPU fallback'
+                        % (what, t.dtype, t.device))
+    return t
+
+
+def _rowmajor(t):
+    """2-D view with unit inner stride (leading dimension = stride(0))."""
+    assert t.dim() == 2
+    if (t.shape[1] > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return max(int(t.stride(0)), int(t.shape[1])) if t.shape[0] > 1 else int(max(t.shape[1], 1))
+
+
+def gemm(A, B, transA=False, transB=False, bias=None, out=None, beta=0, ksplit=1):
+    """out[M,N] (+)= op(A) op(B) (+ bias).  ksplit>1 returns the [ksplit,M,N] partial slabs."""
+    lib = _lib.load()
+    A = _rowmajor(_f32(A, 'gemm A'))
+    B = _rowmajor(_f32(B, 'gemm B'))
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    N, Kb = (B.shape[0], B.shape[1]) if transB else (B.shape[1], B.shape[0])
+    if K != Kb:
+        raise A4NTError('gemm: inner dimensions differ (%d vs %d)' % (K, Kb))
+    if out is None:
+        out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), device=A.device, dtype=torch.float32)
+        ldc = N
+    else:
+        _f32(out, 'gemm out')
+        o2 = out if out.dim() == 2 else out.view(-1, out.shape[-1])
+        assert o2.stride(1) == 1 or o2.shape[1] == 1
+        ldc = _ld(o2)
+    if M == 0 or N == 0:
+        return out
+    if K == 0:
+        if not beta:
+            out.zero_()
+        return out
+    check(lib.a4nt_sgemm(int(transA), int(transB), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc,
+                         _p(bias), int(beta), int(ksplit), M * ldc if ksplit > 1 else 0, _s()), 'a4nt_sgemm')
+    return out
+
+
+def slab_reduce(slabs, c0=0, ncols=None, add=None):
+    """sum over the leading (split-K) axis of slabs[S,R,C_total][:, :, c0:c0+ncols] (+ add)."""
+    lib = _lib.load()
+    S, R, Ct = slabs.shape
+    C = Ct - c0 if ncols is None else ncols
+    out = torch.empty((R, C), device=slabs.device, dtype=torch.float32)
+    check(lib.a4nt_slab_reduce(S, R * Ct, R, C, _p(slabs), Ct, c0, _p(add), C if add is not None else 0, _p(out), C,
+                               _s()), 'a4nt_slab_reduce')
+    return out
+
+
+def _auto_ksplit(M, N, K):
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if tiles >= 192 or K < 1024:
+        return 1
+    return int(max(1, min(256 // tiles, K // 256, 32)))
+
+
+def gemm_auto(A, B, transA=False, transB=False, bias=None):
+    """gemm that splits K (deterministic slab reduction) when the output has too few tiles to fill the chip."""
+    A2, B2 = _rowmajor(A), _rowmajor(B)
+    M, K = (A2.shape[1], A2.shape[0]) if transA else (A2.shape[0], A2.shape[1])
+    N = B2.shape[0] if transB else B2.shape[1]
+    ks = _auto_ksplit(M, N, K)
+    if ks <= 1:
+        return gemm(A2, B2, transA, transB, bias=bias)
+    slabs = gemm(A2, B2, transA, transB, bias=bias, ksplit=ks)
+    return slab_reduce(slabs)
+
+
+def colsum(A, out=None, accumulate=False):
+    lib = _lib.load()
+    A = _rowmajor(_f32(A, 'colsum A'))
+    M, N = A.shape
+    if out is None:
+        out = torch.empty(N, device=A.device, dtype=torch.float32)
+        accumulate = False
+    check(lib.a4nt_colsum(M, N, _p(A), _ld(A), _p(out), int(accumulate), _s()), 'a4nt_colsum')
+    return out
+
+
+def embed_fwd(ids, W, scale=None):
+    lib = _lib.load()
+    ids = ids.contiguous()
+    assert ids.dtype == torch.int64 and ids.is_cuda
+    N, (V, E) = ids.numel(), W.shape
+    out = torch.empty(tuple(ids.shape) + (E,), device=W.device, dtype=torch.float32)
+    check(lib.a4nt_embed_fwd(N, E, V, _p(ids), _p(scale), _p(_f32(W, 'embedding').contiguous()), _p(out), E, _s()),
+          'a4nt_embed_fwd')
+    return out
+
+
+def embed_bwd(ids, dout, dW, scale=None, padding_idx=-1):
+    lib = _lib.load()
+    ids = ids.contiguous()
+    dout = dout.contiguous()
+    V, E = dW.shape
+    check(lib.a4nt_embed_bwd(ids.numel(), E, V, _p(ids), _p(scale), _p(dout), E, _p(dW), int(padding_idx), _s()),
+          'a4nt_embed_bwd')
+    return dW
+
+
+# ----------------------------------------------------------------------------------------------
+# persistent-sweep workspaces (one per device / shape; calls on one stream are ordered)
+# ----------------------------------------------------------------------------------------------
+_ws = {}
+_sync_blocks = []
+
+
+def lstm_geometry(B, H):
+    lib = _lib.load()
+    mt, g = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.a4nt_lstm_geometry(B, H, ctypes.byref(mt), ctypes.byref(g)), 'a4nt_lstm_geometry')
+    return mt.value, g.value
+
+
+def _lstm_ws(dev, B, H, backward):
+    key = (dev.index, B, H, backward)
+    if key not in _ws:
+        lib = _lib.load()
+        _lib.init_device(dev.index if dev.index is not None else torch.cuda.current_device())
+        nf = lib.a4nt_lstm_xch_floats(B, H, int(backward))
+        nw = lib.a4nt_lstm_sync_words(B, H)
+        if nf < 0 or nw < 0:
+            check(1, 'a4nt_lstm workspace')
+        xch = torch.zeros(nf, device=dev, dtype=torch.float32)
+        sync = torch.zeros(nw, device=dev, dtype=torch.int32)
+        _, g = lstm_geometry(B, H)
+        _ws[key] = (xch, sync, g)
+        _sync_blocks.append((sync, g))
+    return _ws[key]
+
+
+def check_timeouts():
+    """Raise if any persistent sweep so far gave up on an inter-workgroup wait (host sync)."""
+    for sync, g in _sync_blocks:
+        if int(sync[32 * g].item()) != 0:
+            sync[32 * g] = 0
+            raise A4NTError('persistent LSTM sweep timed out waiting for a peer workgroup '
+                            '(workgroups not co-resident?); results of that sweep are invalid')
+
+
+def lstm_seq_fwd(gx, w_hh, lens_dev, h0=None, c0=None, gc=None, save=True):
+    """gx: [T,B,4H] pre-activations (overwritten with the activations).  Returns hs_all [T+1,B,H]
+    (row 0 = h0), cs [T,B,H] or None, hN, cN."""
+    lib = _lib.load()
+    T, B, H4 = gx.shape
+    H = H4 // 4
+    dev = gx.device
+    xch, sync, _ = _lstm_ws(dev, B, H, False)
+    hs_all = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
+    if h0 is None:
+        hs_all[0].zero_()
+    else:
+        hs_all[0].copy_(h0)
+    cs = torch.empty((T, B, H), device=dev, dtype=torch.float32) if save else None
+    hN = torch.empty((B, H), device=dev, dtype=torch.float32)
+    cN = torch.empty((B, H), device=dev, dtype=torch.float32)
+    check(lib.a4nt_lstm_seq_fwd(T, B, H, _p(gx), _p(gc), _p(w_hh), _p(h0), _p(c0), _p(lens_dev), _p(hs_all[1:]),
+                                _p(gx) if save else None, _p(cs), _p(hN), _p(cN), _p(xch), _p(sync), _s()),
+          'a4nt_lstm_seq_fwd')
+    return hs_all, cs, hN, cN
+
+
+def lstm_seq_bwd(w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0):
+    lib = _lib.load()
+    T, B, H4 = gates.shape
+    H = H4 // 4
+    dev = gates.device
+    xch, sync, _ = _lstm_ws(dev, B, H, True)
+    dgates = torch.empty_like(gates)
+    dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
+    dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
+    check(lib.a4nt_lstm_seq_bwd(T, B, H, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN), _p(dcN),
+                                _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync), _s()), 'a4nt_lstm_seq_bwd')
+    return dgates, dh0, dc0
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd operators
+# ----------------------------------------------------------------------------------------------
+class _LinearKN(Function):
+    """y = x W + b with W stored [K,N] (decoder_W layout, reference char_translator.py:93-95,279)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_b = b is not None
+        return gemm_auto(x, W, bias=b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = gemm_auto(dy, W, transB=True) if ctx.needs_input_grad[0] else None
+        dW = gemm_auto(x, dy, transA=True) if ctx.needs_input_grad[1] else None
+        db = colsum(dy) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dx, dW, db
+
+
+def linear_kn(x, W, b=None):
+    return _LinearKN.apply(x, W, b)
+
+
+class _LinearNK(Function):
+    """y = x W^T + b with W stored [N,K] (nn.LSTM weight_ih layout)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_b = b is not None
+        return gemm_auto(x, W, transB=True, bias=b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = gemm_auto(dy, W) if ctx.needs_input_grad[0] else None
+        dW = gemm_auto(dy, x, transA=True) if ctx.needs_input_grad[1] else None
+        db = colsum(dy) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dx, dW, db
+
+
+def linear_nk(x, W, b=None):
+    return _LinearNK.apply(x, W, b)
+
+
+class _LstmLayer(Function):
+    """One LSTM layer over a padded, time-major batch with per-row lengths
+    (nn.LSTM over a PackedSequence in the reference: char_translator.py:175-198, char_lstm.py:142-164)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0, c0, gc, lens_dev):
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        x2 = x.reshape(T * B, I)
+        gx = gemm(x2, w_ih, transB=True, bias=(b_ih + b_hh)).view(T, B, 4 * H)
+        hs_all, cs, hN, cN = lstm_seq_fwd(gx, w_hh.contiguous(), lens_dev, h0, c0, gc, save=True)
+        ctx.save_for_backward(x2, w_ih, w_hh, gx, cs, hs_all, c0 if c0 is not None else torch.empty(0), lens_dev
+                              if lens_dev is not None else torch.empty(0))
+        ctx.dims = (T, B, I, H)
+        ctx.flags = (c0 is not None, lens_dev is not None, gc is not None, h0 is not None)
+        return hs_all[1:], hN, cN
+
+    @staticmethod
+    def backward(ctx, dout, dhN, dcN):
+        x2, w_ih, w_hh, gates, cs, hs_all, c0, lens_dev = ctx.saved_tensors
+        T, B, I, H = ctx.dims
+        has_c0, has_lens, has_gc, has_h0 = ctx.flags
+        need_h0 = has_h0 and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6])
+        dout = dout.contiguous() if dout is not None else None
+        dhN = dhN.contiguous() if dhN is not None else None
+        dcN = dcN.contiguous() if dcN is not None else None
+        dgates, dh0, dc0 = lstm_seq_bwd(w_hh.contiguous(), gates, cs, c0 if has_c0 else None,
+                                        lens_dev if has_lens else None, dout, dhN, dcN, need_h0)
+        dG2 = dgates.view(T * B, 4 * H)
+        dx = gemm(dG2, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
+        dw_ih = gemm_auto(dG2, x2, transA=True) if ctx.needs_input_grad[1] else None
+        dw_hh = gemm_auto(dG2, hs_all[:T].view(T * B, H), transA=True) if ctx.needs_input_grad[2] else None
+        db = colsum(dG2) if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
+        dgc = colsum(dgates.view(T, B * 4 * H)).view(B, 4 * H) if (has_gc and ctx.needs_input_grad[7]) else None
+        return dx, dw_ih, dw_hh, db, db, (dh0 if has_h0 else None), (dc0 if has_c0 else None), dgc, None
+
+
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, lens_dev=None, h0=None, c0=None, gc=None):
+    """Returns (out [T,B,H] zero-padded past each row's length, hN [B,H], cN [B,H])."""
+    return _LstmLayer.apply(_f32(x, 'lstm input').contiguous(), w_ih, w_hh, b_ih, b_hh, h0, c0, gc, lens_dev)
+
+
+class _Embed(Function):
+    """nn.Embedding lookup with padding_idx semantics (zero gradient for the padding row)."""
+
+    @staticmethod
+    def forward(ctx, ids, W, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.shape = tuple(W.shape)
+        ctx.padding_idx = padding_idx
+        return embed_fwd(ids, W)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        dW = torch.zeros(ctx.shape, device=dout.device, dtype=torch.float32)
+        embed_bwd(ids, dout, dW, None, ctx.padding_idx)
+        return None, dW, None
+
+
+def embedding(ids, W, padding_idx=-1):
+    return _Embed.apply(ids, W, padding_idx)
+
+
+class _ProjNLL(Function):
+    """mean over valid rows of NLL(log_softmax(h W + b), target): fused vocab projection +
+    log-softmax/NLL (+ the CE backward seed, left in place of the logits)."""
+
+    @staticmethod
+    def forward(ctx, h, W, b, target, n_valid):
+        lib = _lib.load()
+        N, V = h.shape[0], W.shape[1]
+        logits = gemm(h, W, bias=b)
+        loss_rows = torch.empty(N, device=h.device, dtype=torch.float32)
+        check(lib.a4nt_nll_rows(N, V, _p(logits), V, _p(target), 1.0 / float(n_valid), _p(loss_rows), 1, _s()),
+              'a4nt_nll_rows')
+        ctx.save_for_backward(h, W, logits)
+        return loss_rows.sum() / float(n_valid)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, W, dlogits = ctx.saved_tensors
+        dh = gemm(dlogits, W, transB=True) if ctx.needs_input_grad[0] else None
+        dW = gemm_auto(h, dlogits, transA=True) if ctx.needs_input_grad[1] else None
+        db = colsum(dlogits) if ctx.needs_input_grad[2] else None
+        return (dh * g if dh is not None else None, dW * g if dW is not None else None,
+                db * g if db is not None else None, None, None)
+
+
+def proj_nll(h, W, b, target, n_valid):
+    """h [N,H]; target [N] int64 with -1 for rows to ignore; n_valid = number of counted rows."""
+    return _ProjNLL.apply(h.contiguous(), W, b, target.contiguous(), n_valid)
+
+
+def gumbel_rows(logits, U, seed, step, scale, tau, hard, greedy, y, stats, tok, val_in, val_out, gen_lens, done,
+                end_c, dense=None):
+    lib = _lib.load()
+    B, V = logits.shape
+    check(lib.a4nt_gumbel_fwd(B, V, _p(logits), _ld(logits), _p(U), V if U is not None else 0, int(seed), int(step),
+                              float(scale), float(tau), int(hard), int(greedy), _p(y), V, _p(stats), _p(tok),
+                              _p(val_in), _p(val_out), _p(gen_lens), _p(done), int(end_c), _p(dense),
+                              V if dense is not None else 0, _s()), 'a4nt_gumbel_fwd')
+
+
+def gumbel_bwd_rows(ds, y, stats, coef):
+    lib = _lib.load()
+    B, V = ds.shape
+    check(lib.a4nt_gumbel_bwd(B, V, _p(ds), _ld(ds), _p(y), V, _p(stats), float(coef), _s()), 'a4nt_gumbel_bwd')
+
+
+class _GumbelDense(Function):
+    """gumbel_softmax_sample on a [B,V] logit matrix returning the dense sample (generic path:
+    soft (non straight-through) samples, stacked decoders).  x is already scaled by softmax_scale."""
+
+    @staticmethod
+    def forward(ctx, x, U, seed, step, tau, hard):
+        B, V = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        stats = torch.empty((B, 2), device=x.device, dtype=torch.float32)
+        tok = torch.empty(B, device=x.device, dtype=torch.int64)
+        dense = torch.empty_like(x)
+        gumbel_rows(x, U, seed, step, 1.0, tau, hard, 0, y, stats, tok, None, None, None, None, -1, dense)
+        ctx.save_for_backward(y, stats)
+        ctx.tau = tau
+        ctx.mark_non_differentiable(tok)
+        return dense, tok
+
+    @staticmethod
+    def backward(ctx, dd, _dtok):
+        y, stats = ctx.saved_tensors
+        ds = dd.contiguous().clone()
+        gumbel_bwd_rows(ds, y, stats, 1.0 / ctx.tau)
+        return ds, None, None, None, None, None
+
+
+def gumbel_dense(x, U, seed, step, tau, hard):
+    return _GumbelDense.apply(x, U, seed, step, tau, hard)

@@ -1,0 +1,136 @@
+/*
+ * a4nt_hip.h -- C ABI of liba4nt_hip.so: the hand-written gfx950 (MI355X) kernels behind the
+ * A4NT adversarial-training hot path.
+ *
+ * The reference (rakshithShetty/A4NT-author-masking) has no FFI layer: its hot path is PyTorch
+ * ops called from four Python model files.  Each entry point below therefore cites the reference
+ * call site(s) whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory the caller owns (the Python host allocates it
+ *     with torch and passes tensor.data_ptr()); the library never allocates or frees;
+ *   - matrices are row-major fp32 with an explicit leading dimension (in elements);
+ *   - `stream` is a hipStream_t; kernels are enqueued on it and the call returns immediately;
+ *   - return value: 0 = ok, 1 = bad argument, 2 = HIP launch error, 3 = persistent-kernel
+ *     hand-off timeout; a4nt_last_error() returns the message of the calling thread's last error;
+ *   - token ids are int64 (torch.LongTensor), lengths int32.
+ */
+#ifndef A4NT_HIP_H
+#define A4NT_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* a4nt_last_error(void);
+int a4nt_version(void);
+/* Verifies `device` is gfx950 with 256 CUs (the persistent sweeps assume 256 co-resident
+ * workgroups).  Replaces nothing in the reference (it hard-codes .cuda(), char_lstm.py:98). */
+int a4nt_init(int device, int* num_cus);
+
+/* C[M,N] (+)= op(A) * op(B) (+ bias[N]) on v_mfma_f32_32x32x2_f32.
+ *   transA=0: A is [M][K];  transA=1: A is stored [K][M].   transB=0: B is [K][N]; transB=1: [N][K].
+ *   beta in {0,1}.  ksplit>1 writes ksplit partial slabs at C + z*slab_stride (beta must be 0).
+ * Replaces: x.mm(W) of the vocab projection (char_translator.py:279,377), the soft-embedding
+ * contractions (char_translator.py:214,299,329,381; char_lstm.py:289; char_cnn.py:73), the
+ * x*W_ih^T half of nn.LSTM (char_translator.py:182-197; char_lstm.py:148-163), nn.Conv1d as
+ * shifted GEMMs (char_cnn.py:84), the classifier heads (char_lstm.py:329; char_cnn.py:96) and
+ * every autograd backward of those. */
+int a4nt_sgemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+               float* C, int ldc, const float* bias, int beta, int ksplit, long long slab_stride, void* stream);
+
+/* Geometry of the persistent LSTM sweeps for a batch of B rows and hidden size H
+ * (H multiple of 64, 64..512): rows per group = 16*mt, groups*(H/16) workgroups <= 256. */
+int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out);
+long long a4nt_lstm_xch_floats(int B, int H, int backward);   /* exchange-buffer size (floats) */
+int a4nt_lstm_sync_words(int B, int H);                       /* sync-block size (uint32 words) */
+
+/* Persistent forward sweep of ONE LSTM layer over T steps (W_hh resident in VGPRs, recurrent
+ * contraction on v_mfma_f32_16x16x4_f32, fused gate non-linearity / cell update).
+ *   gx    [T][B][4H]  x_t*W_ih^T + b_ih + b_hh (gate order i,f,g,o), from a4nt_sgemm
+ *   gc    [B][4H] or NULL: loop-invariant term added to every step's gates (the decoder's
+ *                     ctxt*W_ic^T, char_translator.py:258, hoisted out of the time loop)
+ *   whh   [4H][H]     16-byte aligned
+ *   h0,c0 [B][H] or NULL (zeros);  lens [B] or NULL (every row runs T steps; rows need no order)
+ *   hs    [T][B][H]   outputs, zero where t >= lens[b] (pad_packed_sequence semantics)
+ *   gates [T][B][4H]  post-activation gates saved for BPTT (may alias gx) or NULL
+ *   cs    [T][B][H]   cell states saved for BPTT or NULL
+ *   hN,cN [B][H]      state at each row's own last step or NULL
+ *   xch, sync         scratch sized by a4nt_lstm_xch_floats(B,H,0) / a4nt_lstm_sync_words
+ * Replaces: nn.LSTM over a PackedSequence, one layer (char_translator.py:175-198 as used at
+ * :221,:266,:305,:335; char_lstm.py:142-164 as used at :296). */
+int a4nt_lstm_seq_fwd(int T, int B, int H, const float* gx, const float* gc, const float* whh, const float* h0, const float* c0,
+                      const int* lens, float* hs, float* gates, float* cs, float* hN, float* cN, float* xch,
+                      unsigned* sync, void* stream);
+
+/* Persistent backward sweep (BPTT) of one layer.  dgates [T][B][4H] receives the gradient w.r.t.
+ * the pre-activation gates (zero where t >= lens[b]; may alias gates); weight / input gradients
+ * are time-batched a4nt_sgemm calls over it.  dhs / dhN / dcN may be NULL.  dh0 NULL skips the
+ * last recurrent product.  xch sized by a4nt_lstm_xch_floats(B,H,1).
+ * Replaces: autograd backward of the nn.LSTM calls cited above. */
+int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const float* gates, const float* cs, const float* c0,
+                      const int* lens, const float* dhs, const float* dhN, const float* dcN, float* dgates,
+                      float* dh0, float* dc0, float* xch, unsigned* sync, void* stream);
+/* Synchronises `stream` and reports A4NT_ERR_TIMEOUT if a sweep raised its timeout word. */
+int a4nt_lstm_check_timeout(const unsigned* sync, int groups, void* stream);
+
+/* One step of the free-running decoder (first layer): gates = cg[b] + val[b]*ptab[tok[b]] +
+ * h_{t-1}*W_hh^T, fused cell update.  h_{t-1} is read from / h_t published to xch (fragment
+ * layout, parity = step&1; zero xch before step 0).  c_prev NULL = zeros.
+ * Replaces: the single-step nn.LSTM call inside the generation loop (char_translator.py:360,398)
+ * with the loop-invariant ctxt part hoisted (cg) and emb*W_ie^T tabulated per token (ptab). */
+int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const float* ptab, const long long* tok,
+                       const float* val, const float* whh, const float* c_prev, float* h_out, float* gates_out,
+                       float* c_out, float* xch, void* stream);
+
+/* Element-wise cell backward of one decoder step (reverse loop of the generator). */
+int a4nt_lstm_cell_bwd(int B, int H, const float* gates, const float* c_t, const float* c_prev, const float* dh_a,
+                       const float* dh_b, float* dc_io, float* dgates, void* stream);
+
+/* Gumbel-softmax sampling row kernel: scale, log_softmax, Gumbel noise (injected uniforms U or
+ * Philox(seed, step, row, v)), /tau, softmax statistics, argmax, straight-through one-hot value,
+ * gen_lens / done bookkeeping; greedy=1: plain argmax of the logits.
+ * Replaces: sample_gumbel + gumbel_softmax_sample (char_translator.py:10-28) and the loop body
+ * char_translator.py:379-392. */
+int a4nt_gumbel_fwd(int B, int V, const float* logits, int ldl, const float* U, int ldu, unsigned long long seed,
+                    unsigned step, float scale, float tau, int hard, int greedy, float* y, int ldy, float* stats,
+                    long long* tok, float* val_in, float* val_out, int* gen_lens, unsigned char* done,
+                    long long end_c, float* dense, int ldd, void* stream);
+/* In place: ds -> dlogits = coef * p * (ds - <p,ds>), p = softmax(y) from the saved y / stats.
+ * Replaces: autograd backward of gumbel_softmax_sample (char_translator.py:17-28). */
+int a4nt_gumbel_bwd(int B, int V, float* ds, int ldd, const float* y, int ldy, const float* stats, float coef,
+                    void* stream);
+
+/* Fused log-softmax + NLL over N rows; leaves (softmax - onehot)*gscale in place of the logits when
+ * write_grad.  target < 0 ignores the row.
+ * Replaces: nn.CrossEntropyLoss over packed scores (train_translator.py:112-113;
+ * train_adversarial_translator.py:661-664) and its backward. */
+int a4nt_nll_rows(int N, int V, float* logits, int ld, const long long* target, float gscale, float* loss_rows,
+                  int write_grad, void* stream);
+
+/* Embedding gather out[n] = scale[n]*W[ids[n]] and its scatter-add backward (padding_idx row skipped).
+ * Replaces: nn.Embedding lookups (char_translator.py:212,250,327,349,389; char_lstm.py:280;
+ * char_cnn.py:71) and, with scale = straight-through sample value, samp.mm(char_emb.weight) for
+ * one-hot samples (char_translator.py:381; char_lstm.py:289). */
+int a4nt_embed_fwd(long long N, int E, int V, const long long* ids, const float* scale, const float* W, float* out,
+                   int ldo, void* stream);
+int a4nt_embed_bwd(long long N, int E, int V, const long long* ids, const float* scale, const float* dout, int ldd,
+                   float* dW, long long padding_idx, void* stream);
+
+/* out[n] (+)= sum_m A[m][n]  (bias gradients). */
+int a4nt_colsum(int M, int N, const float* A, int lda, float* out, int accumulate, void* stream);
+/* out[r][c] = sum_s slabs[s*stride + r*lds + c0 + c] (+ add[r][c])  (split-K reduction). */
+int a4nt_slab_reduce(int S, long long stride, int R, int C, const float* slabs, int lds, int c0, const float* add,
+                     int lda, float* out, int ldo, void* stream);
+
+/* CharCNN epilogue: leaky_relu + (zero-padded) max over time of [Tout][B][F] conv pre-activations,
+ * and its backward (in place over pre).  Replaces: FN.leaky_relu + FN.pad + FN.max_pool1d
+ * (char_cnn.py:84-92). */
+int a4nt_lrelu_maxtime(int Tout, int B, int F, const float* pre, int ldp, float slope, int pad, float* feat, int ldf,
+                       int* argmax, void* stream);
+int a4nt_lrelu_maxtime_bwd(int Tout, int B, int F, float* pre, int ldp, float slope, const float* dfeat, int ldf,
+                           const int* argmax, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

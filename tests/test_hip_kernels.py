@@ -1,0 +1,209 @@
+"""GPU: every C-ABI kernel against a plain fp32 torch (CPU) computation of the same operator.
+
+Tolerances are max-normalised errors (max|a-b| / max|b|), fp32 noise floor of SURVEY.md Appendix B:
+1e-5 on forward values, 5e-5 on gradients.
+"""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+from golden_util import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL, TOLG = 1e-5, 5e-5
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import a4nt_amd
+    from a4nt_amd import ops as o
+    return o
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 1034),
+                                   (128, 10001, 512), (300, 2048, 98), (2048, 512, 700)])
+@pytest.mark.parametrize('tA,tB', [(0, 0), (0, 1), (1, 0)])
+def test_sgemm(ops, M, N, K, tA, tB):
+    A = _rand(K, M, seed=1) if tA else _rand(M, K, seed=1)
+    B = _rand(N, K, seed=2) if tB else _rand(K, N, seed=2)
+    bias = _rand(N, seed=3)
+    ref = (A.t() if tA else A).double() @ (B.t() if tB else B).double() + bias.double()
+    out = ops.gemm(A.cuda(), B.cuda(), bool(tA), bool(tB), bias=bias.cuda())
+    assert_close(out, ref.float(), 2e-6, 'sgemm')
+    # accumulate + strided operands (leading dimension > width, unaligned base)
+    big = _rand(M + 3, N + 5, seed=4).cuda()
+    view = big[1:M + 1, 3:N + 3]
+    before = view.clone()
+    ops.gemm(A.cuda(), B.cuda(), bool(tA), bool(tB), out=view, beta=1)
+    assert_close(view, (before.cpu().double() + ref - bias.double()).float(), 2e-6, 'sgemm beta=1 strided')
+    assert torch.equal(big[0], _rand(M + 3, N + 5, seed=4)[0].cuda()), 'sgemm wrote outside its output'
+
+
+def test_sgemm_splitk(ops):
+    A, B = _rand(128, 10001, seed=5), _rand(512, 10001, seed=6)
+    ref = A.double() @ B.double().t()
+    slabs = ops.gemm(A.cuda(), B.cuda(), transB=True, ksplit=16)
+    assert slabs.shape == (16, 128, 512)
+    assert_close(ops.slab_reduce(slabs), ref.float(), 2e-6, 'split-K')
+    add = _rand(128, 100, seed=7)
+    assert_close(ops.slab_reduce(slabs, 30, 100, add.cuda()), (ref[:, 30:130] + add.double()).float(), 2e-6,
+                 'slab_reduce window')
+    assert_close(ops.gemm_auto(A.cuda(), B.cuda(), transB=True), ref.float(), 2e-6, 'gemm_auto')
+
+
+def test_colsum_embed(ops):
+    A = _rand(1000, 333, seed=8)
+    assert_close(ops.colsum(A.cuda()), A.double().sum(0).float(), 2e-6, 'colsum')
+    W = _rand(51, 24, seed=9)
+    ids = torch.randint(0, 51, (7, 5), generator=torch.Generator().manual_seed(1))
+    sc = _rand(7, 5, seed=10)
+    out = ops.embed_fwd(ids.cuda(), W.cuda(), sc.cuda())
+    assert_close(out, sc.unsqueeze(-1) * W[ids], 1e-7, 'embed_fwd')
+    dout = _rand(7, 5, 24, seed=11)
+    dW = torch.zeros(51, 24).cuda()
+    ops.embed_bwd(ids.cuda(), dout.cuda(), dW, sc.cuda(), 0)
+    ref = torch.zeros(51, 24).index_add_(0, ids.view(-1), (sc.unsqueeze(-1) * dout).view(-1, 24))
+    ref[0] = 0
+    assert_close(dW, ref, 2e-6, 'embed_bwd')
+
+
+# ------------------------------------------------------------------------------------------
+def _ref_lstm(x, lens, lstm, h0, c0, up, uph, upc):
+    """torch CPU nn.LSTM over a packed batch (rows sorted by length for packing, then unsorted)."""
+    x = x.clone().requires_grad_(True)
+    packed = pack_padded_sequence(x, lens, enforce_sorted=False)
+    out_p, (hN, cN) = lstm(packed, (h0.unsqueeze(0), c0.unsqueeze(0)))
+    out, _ = pad_packed_sequence(out_p, total_length=x.shape[0])
+    loss = (out * up).sum() + (hN[0] * uph).sum() + (cN[0] * upc).sum()
+    lstm.zero_grad()
+    loss.backward()
+    return out.detach(), hN[0].detach(), cN[0].detach(), x.grad
+
+
+@pytest.mark.parametrize('T,B,I,H,ragged', [(7, 5, 24, 64, True), (9, 20, 33, 128, True), (6, 40, 16, 64, True),
+                                            (12, 128, 64, 512, False), (10, 70, 48, 256, True),
+                                            (5, 300, 16, 64, True)])
+def test_lstm_layer_fwd_bwd(ops, T, B, I, H, ragged):
+    g = torch.Generator().manual_seed(T * 1000 + B)
+    lstm = nn.LSTM(I, H, 1)
+    x = _rand(T, B, I, seed=21)
+    lens = [int(v) for v in torch.randint(1, T + 1, (B,), generator=g)] if ragged else [T] * B
+    if ragged:
+        lens[B // 2] = T
+    h0, c0 = _rand(B, H, seed=22, scale=0.5), _rand(B, H, seed=23, scale=0.5)
+    up, uph, upc = _rand(T, B, H, seed=24), _rand(B, H, seed=25), _rand(B, H, seed=26)
+    out_r, hN_r, cN_r, dx_r = _ref_lstm(x, lens, lstm, h0, c0, up, uph, upc)
+
+    P = {k: v.detach().clone().cuda().requires_grad_(True) for k, v in lstm.named_parameters()}
+    xg = x.cuda().requires_grad_(True)
+    h0g, c0g = h0.cuda().requires_grad_(True), c0.cuda().requires_grad_(True)
+    lens_dev = torch.tensor(lens, dtype=torch.int32).cuda() if ragged else None
+    out, hN, cN = ops.lstm_layer(xg, P['weight_ih_l0'], P['weight_hh_l0'], P['bias_ih_l0'], P['bias_hh_l0'], lens_dev,
+                                 h0g, c0g)
+    loss = (out * up.cuda()).sum() + (hN * uph.cuda()).sum() + (cN * upc.cuda()).sum()
+    loss.backward()
+    ops.check_timeouts()
+    assert_close(out, out_r, TOL, 'lstm out')
+    assert_close(hN, hN_r, TOL, 'lstm hN')
+    assert_close(cN, cN_r, TOL, 'lstm cN')
+    assert_close(xg.grad, dx_r, TOLG, 'lstm dx')
+    for k, v in lstm.named_parameters():
+        assert_close(P[k].grad, v.grad, TOLG, 'lstm d' + k)
+    # gradients w.r.t. the initial state
+    h0c, c0c = h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    packed = pack_padded_sequence(x, lens, enforce_sorted=False)
+    o_p, (hh, cc) = lstm(packed, (h0c.unsqueeze(0), c0c.unsqueeze(0)))
+    o, _ = pad_packed_sequence(o_p, total_length=T)
+    ((o * up).sum() + (hh[0] * uph).sum() + (cc[0] * upc).sum()).backward()
+    assert_close(h0g.grad, h0c.grad, TOLG, 'lstm dh0')
+    assert_close(c0g.grad, c0c.grad, TOLG, 'lstm dc0')
+
+
+def test_lstm_loop_invariant_gate_term(ops):
+    """gc: the hoisted ctxt*W_ic^T term equals feeding [ctxt, x_t] at every step."""
+    T, B, I, Hc, H = 6, 9, 20, 30, 64
+    lstm = nn.LSTM(Hc + I, H, 1)
+    x, ctxt = _rand(T, B, I, seed=31), _rand(B, Hc, seed=32)
+    full = torch.cat([ctxt.unsqueeze(0).expand(T, B, Hc), x], -1)
+    out_r, _ = lstm(full)
+    w = lstm.weight_ih_l0.detach().cuda()
+    gc = ops.gemm(ctxt.cuda(), w[:, :Hc], transB=True)
+    out, _, _ = ops.lstm_layer(x.cuda(), w[:, Hc:].contiguous(), lstm.weight_hh_l0.detach().cuda(),
+                               lstm.bias_ih_l0.detach().cuda(), lstm.bias_hh_l0.detach().cuda(), None, None, None, gc)
+    assert_close(out, out_r.detach(), TOL, 'lstm with gc')
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('hard', [0, 1])
+def test_gumbel_dense_vs_golden(ops, hard):
+    from golden_util import Fixture
+    fx = Fixture('gumbel_hard%d' % hard)
+    x = fx.t('x', 'cuda').requires_grad_(True)
+    y, tok = ops.gumbel_dense(x, fx.t('u', 'cuda'), 0, 0, float(fx.params['tau']), bool(hard))
+    (y * fx.t('upstream', 'cuda')).sum().backward()
+    assert_close(y, fx.t('y'), TOL, 'gumbel y')
+    assert torch.equal(tok.cpu(), fx.t('y').argmax(1))
+    assert_close(x.grad, fx.t('dx'), TOLG, 'gumbel dx')
+
+
+def test_gumbel_philox_uniformity(ops):
+    """On-device Philox noise: argmax frequencies of flat logits are uniform; streams differ by step."""
+    B, V = 256, 64
+    x = torch.zeros(B, V).cuda()
+    counts = torch.zeros(V)
+    toks = []
+    for step in range(40):
+        _, tok = ops.gumbel_dense(x, None, 1234, step, 1.0, True)
+        toks.append(tok.cpu())
+        counts += torch.bincount(tok.cpu(), minlength=V).float()
+    assert not torch.equal(toks[0], toks[1])
+    expected = B * 40 / V
+    assert counts.min() > 0.6 * expected and counts.max() < 1.4 * expected
+
+
+def test_proj_nll(ops):
+    N, H, V = 37, 64, 301
+    h, W, b = _rand(N, H, seed=41), _rand(H, V, seed=42, scale=0.3), _rand(V, seed=43)
+    tgt = torch.randint(0, V, (N,), generator=torch.Generator().manual_seed(2))
+    tgt[5] = -1
+    tgt[20] = -1
+    hc, Wc, bc = (t.clone().requires_grad_(True) for t in (h, W, b))
+    ref = F.cross_entropy(hc @ Wc + bc, tgt, ignore_index=-1)
+    (ref * 1.7).backward()
+    hg, Wg, bg = (t.cuda().requires_grad_(True) for t in (h, W, b))
+    loss = ops.proj_nll(hg, Wg, bg, tgt.cuda(), int((tgt >= 0).sum()))
+    (loss * 1.7).backward()
+    assert_close(loss, ref.detach(), TOL, 'nll loss')
+    for a, r, n in ((hg, hc, 'dh'), (Wg, Wc, 'dW'), (bg, bc, 'db')):
+        assert_close(a.grad, r.grad, TOLG, 'nll ' + n)
+
+
+@pytest.mark.parametrize('K', [2, 3, 4, 5])
+def test_conv1d_time_major(ops, K):
+    from a4nt_amd.char_cnn import _Conv1dTM, _LreluMaxTime
+    T, B, C, Fo = 9, 5, 24, 12
+    conv = nn.Conv1d(C, Fo, K, padding=K // 2)
+    x = _rand(T, B, C, seed=51)
+    xc = x.clone().requires_grad_(True)
+    pre_r = conv(xc.permute(1, 2, 0))                       # [B,F,Tout]
+    feat_r = F.pad(F.leaky_relu(pre_r), (1, 1)).max(dim=2)[0]
+    up = _rand(B, Fo, seed=52)
+    (feat_r * up).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    wg, bg = conv.weight.detach().cuda().requires_grad_(True), conv.bias.detach().cuda().requires_grad_(True)
+    pre = _Conv1dTM.apply(xg, wg, bg)
+    assert_close(pre, pre_r.detach().permute(2, 0, 1), TOL, 'conv pre')
+    feat = _LreluMaxTime.apply(pre, 2, 0.01)
+    (feat * up.cuda()).sum().backward()
+    assert_close(feat, feat_r.detach(), TOL, 'conv feat')
+    assert_close(xg.grad, xc.grad, TOLG, 'conv dx')
+    assert_close(wg.grad, conv.weight.grad, TOLG, 'conv dW')
+    assert_close(bg.grad, conv.bias.grad, TOLG, 'conv db')

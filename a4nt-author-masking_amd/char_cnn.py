@@ -163,7 +163,14 @@ class CharCNN(nn.Module):
                 max_sz = pres[-1].shape[0]
                 res_here = self.decoder_cnn_residual and i > 0 and (i % 2) == 0
                 if i == self.n_layers - 1 and not drop_active and not res_here:
-                    feat = torch.cat([_LreluMaxTime.apply(p, max_sz - p.shape[0], 0.01) for p in pres], dim=1)
+                    feats = []
+                    for p in pres:
+                        d = max_sz - p.shape[0]
+                        left, right = d // 2, int((d / 2. + 0.5) // 1)
+                        # a negative pad crops (FN.pad semantics, char_cnn.py:86: branch longer than the last one)
+                        p = p[max(0, -left):p.shape[0] - max(0, -right)]
+                        feats.append(_LreluMaxTime.apply(p, max(0, left) + max(0, right), 0.01))
+                    feat = torch.cat(feats, dim=1)
                     break
                 padded = []
                 for p in pres:

@@ -31,6 +31,30 @@ def _f32(t, what):
     return t
 
 
+# Optional per-kernel timing for bench.py's roofline line: TIMER = {'name': <kernel family>, 'events': []}.
+# Events are recorded on torch's current stream, which is the stream every kernel here is launched on.
+TIMER = None
+
+
+class _Timed(object):
+    def __init__(self, name, flops):
+        self.on = TIMER is not None and TIMER['name'] == name
+        self.flops = flops
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            TIMER['events'].append((self.e0, self.e1, self.flops))
+        return False
+
+
 def _rowmajor(t):
     """2-D view with unit inner stride (leading dimension = stride(0))."""
     assert t.dim() == 2
@@ -66,8 +90,9 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, beta=0, ksplit=1
         if not beta:
             out.zero_()
         return out
-    check(lib.a4nt_sgemm(int(transA), int(transB), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc,
-                         _p(bias), int(beta), int(ksplit), M * ldc if ksplit > 1 else 0, _s()), 'a4nt_sgemm')
+    with _Timed('sgemm', 2.0 * M * N * K):
+        check(lib.a4nt_sgemm(int(transA), int(transB), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc,
+                             _p(bias), int(beta), int(ksplit), M * ldc if ksplit > 1 else 0, _s()), 'a4nt_sgemm')
     return out
 
 
@@ -189,9 +214,10 @@ def lstm_seq_fwd(gx, w_hh, lens_dev, h0=None, c0=None, gc=None, save=True):
     cs = torch.empty((T, B, H), device=dev, dtype=torch.float32) if save else None
     hN = torch.empty((B, H), device=dev, dtype=torch.float32)
     cN = torch.empty((B, H), device=dev, dtype=torch.float32)
-    check(lib.a4nt_lstm_seq_fwd(T, B, H, _p(gx), _p(gc), _p(w_hh), _p(h0), _p(c0), _p(lens_dev), _p(hs_all[1:]),
-                                _p(gx) if save else None, _p(cs), _p(hN), _p(cN), _p(xch), _p(sync), _s()),
-          'a4nt_lstm_seq_fwd')
+    with _Timed('lstm_seq_fwd', 8.0 * T * B * H * H):
+        check(lib.a4nt_lstm_seq_fwd(T, B, H, _p(gx), _p(gc), _p(w_hh), _p(h0), _p(c0), _p(lens_dev), _p(hs_all[1:]),
+                                    _p(gx) if save else None, _p(cs), _p(hN), _p(cN), _p(xch), _p(sync), _s()),
+              'a4nt_lstm_seq_fwd')
     return hs_all, cs, hN, cN
 
 
@@ -204,8 +230,9 @@ def lstm_seq_bwd(w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0):
     dgates = torch.empty_like(gates)
     dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
     dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
-    check(lib.a4nt_lstm_seq_bwd(T, B, H, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN), _p(dcN),
-                                _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync), _s()), 'a4nt_lstm_seq_bwd')
+    with _Timed('lstm_seq_bwd', 8.0 * T * B * H * H):
+        check(lib.a4nt_lstm_seq_bwd(T, B, H, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN),
+                                    _p(dcN), _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync), _s()), 'a4nt_lstm_seq_bwd')
     return dgates, dh0, dc0
 
 

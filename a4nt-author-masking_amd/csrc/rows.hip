@@ -8,21 +8,26 @@
 //                  (softmax - onehot) * gscale in place of the logits (fused CE backward)
 #include "common.h"
 
+#define ROWS_MAXW 16
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
     if (lane == 0) red[w] = v;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
 }
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
     if (lane == 0) red[w] = v;
     __syncthreads();
-    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float m = red[0];
+    for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
+    return m;
 }
 
 // Philox4x32-10 (Salmon et al.), counter = (elem/4, row, step, 0), key = seed
@@ -59,32 +64,50 @@ struct GumbelFwdArgs {
     float* dense; int ldd; int hard;   // optional dense sample row (generic path)
 };
 
-__global__ __launch_bounds__(256) void gumbel_fwd_kernel(GumbelFwdArgs a) {
-    __shared__ float red[4];
-    __shared__ int redi[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(1024) void gumbel_fwd_kernel(GumbelFwdArgs a) {
+    __shared__ float red[ROWS_MAXW];
+    __shared__ int redi[ROWS_MAXW];
+    const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const float* x = a.logits + (long long)b * a.ldl;
     const int V = a.V;
     float best = -INFINITY; int besti = 0x7fffffff;
 
     if (a.greedy) {
-        for (int v = tid; v < V; v += 256) { const float f = x[v]; if (f > best) { best = f; besti = v; } }
+        for (int v = tid; v < V; v += NT) { const float f = x[v]; if (f > best) { best = f; besti = v; } }
     } else {
         float m1 = -INFINITY;
-        for (int v = tid; v < V; v += 256) m1 = fmaxf(m1, x[v] * a.scale);
+        for (int v = tid; v < V; v += NT) m1 = fmaxf(m1, x[v] * a.scale);
         m1 = block_max(m1, red);
         float s1 = 0.f;
-        for (int v = tid; v < V; v += 256) s1 += expf(x[v] * a.scale - m1);
+        for (int v = tid; v < V; v += NT) s1 += expf(x[v] * a.scale - m1);
         s1 = block_sum(s1, red);
         const float lse = logf(s1);
         float* y = a.y + (long long)b * a.ldy;
-        for (int v = tid; v < V; v += 256) {
-            const float u = a.U ? a.U[(long long)b * a.ldu + v] : uniform_at(a.seed, a.step, (unsigned)b, (unsigned)v);
-            const float gn = -logf(-logf(u + 1e-20f) + 1e-20f);
-            const float lsm = (x[v] * a.scale - m1) - lse;
-            const float yy = (lsm + gn) / a.tau;
-            y[v] = yy;
-            if (yy > best) { best = yy; besti = v; }
+        if (a.U) {
+            for (int v = tid; v < V; v += NT) {
+                const float u = a.U[(long long)b * a.ldu + v];
+                const float gn = -logf(-logf(u + 1e-20f) + 1e-20f);
+                const float yy = (((x[v] * a.scale - m1) - lse) + gn) / a.tau;
+                y[v] = yy;
+                if (yy > best) { best = yy; besti = v; }
+            }
+        } else {
+            // one Philox4x32-10 call feeds 4 consecutive vocabulary entries
+            for (int v4 = tid * 4; v4 < V; v4 += NT * 4) {
+                unsigned o[4];
+                philox4((unsigned)(v4 >> 2), (unsigned)b, a.step, 0u, (unsigned)a.seed, (unsigned)(a.seed >> 32), o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int v = v4 + i;
+                    if (v < V) {
+                        const float u = (float)(o[i] >> 8) * (1.0f / 16777216.0f);
+                        const float gn = -logf(-logf(u + 1e-20f) + 1e-20f);
+                        const float yy = (((x[v] * a.scale - m1) - lse) + gn) / a.tau;
+                        y[v] = yy;
+                        if (yy > best) { best = yy; besti = v; }
+                    }
+                }
+            }
         }
     }
     // block argmax, lowest index on ties
@@ -96,14 +119,16 @@ __global__ __launch_bounds__(256) void gumbel_fwd_kernel(GumbelFwdArgs a) {
         __syncthreads();
         if ((tid & 63) == 0) redi[tid >> 6] = cand;
         __syncthreads();
-        besti = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+        besti = redi[0];
+        for (int i = 1; i < (NT >> 6); ++i) besti = min(besti, redi[i]);
         best = bm;
     }
     float hot = 1.0f, s2 = 1.0f;
     if (!a.greedy) {
         const float* y = a.y + (long long)b * a.ldy;
         float s = 0.f;
-        for (int v = tid; v < V; v += 256) s += expf(y[v] - best);
+        // y was written by this workgroup (possibly other threads): the block_max barriers above order it
+        for (int v = tid; v < V; v += NT) s += expf(y[v] - best);
         s2 = block_sum(s, red);
         const float p_hot = 1.0f / s2;                 // exp(0) / sum
         hot = a.hard ? ((1.0f - p_hot) + p_hot) : p_hot;   // (one_hot - ysft.data) + ysft at the hot index
@@ -112,10 +137,10 @@ __global__ __launch_bounds__(256) void gumbel_fwd_kernel(GumbelFwdArgs a) {
     if (a.dense) {
         float* d = a.dense + (long long)b * a.ldd;
         if (a.hard) {
-            for (int v = tid; v < V; v += 256) d[v] = (v == besti) ? hot : 0.f;
+            for (int v = tid; v < V; v += NT) d[v] = (v == besti) ? hot : 0.f;
         } else {
             const float* y = a.y + (long long)b * a.ldy;
-            for (int v = tid; v < V; v += 256) d[v] = expf(y[v] - best) / s2;
+            for (int v = tid; v < V; v += NT) d[v] = expf(y[v] - best) / s2;
         }
     }
     if (tid == 0) {
@@ -143,56 +168,56 @@ extern "C" int a4nt_gumbel_fwd(int B, int V, const float* logits, int ldl, const
     a.tau = tau; a.greedy = greedy; a.y = y; a.ldy = ldy; a.stats = stats; a.tok = tok; a.val_in = val_in;
     a.val_out = val_out; a.gen_lens = gen_lens; a.done = done; a.end_c = end_c; a.dense = dense; a.ldd = ldd;
     a.hard = hard;
-    hipLaunchKernelGGL(gumbel_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gumbel_fwd_kernel, dim3(B), dim3(V >= 4096 ? 1024 : 256), 0, (hipStream_t)stream, a);
     return a4nt_check_launch("gumbel_fwd");
 }
 
 // ds (in) -> dlogits (out, in place).  p = exp(y - stats[0]) / stats[1].
-__global__ __launch_bounds__(256) void gumbel_bwd_kernel(int V, float* ds, int ldd, const float* y, int ldy,
+__global__ __launch_bounds__(1024) void gumbel_bwd_kernel(int V, float* ds, int ldd, const float* y, int ldy,
                                                          const float* stats, float coef) {
-    __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[ROWS_MAXW];
+    const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     float* d = ds + (long long)b * ldd;
     const float* yy = y + (long long)b * ldy;
     const float m2 = stats[2 * b], inv = 1.0f / stats[2 * b + 1];
     float dot = 0.f;
-    for (int v = tid; v < V; v += 256) dot += (expf(yy[v] - m2) * inv) * d[v];
+    for (int v = tid; v < V; v += NT) dot += (expf(yy[v] - m2) * inv) * d[v];
     dot = block_sum(dot, red);
-    for (int v = tid; v < V; v += 256) d[v] = coef * (expf(yy[v] - m2) * inv) * (d[v] - dot);
+    for (int v = tid; v < V; v += NT) d[v] = coef * (expf(yy[v] - m2) * inv) * (d[v] - dot);
 }
 
 extern "C" int a4nt_gumbel_bwd(int B, int V, float* ds, int ldd, const float* y, int ldy, const float* stats,
                                float coef, void* stream) {
     if (B <= 0) return A4NT_OK;
     if (V <= 0 || !ds || !y || !stats) { a4nt_set_error("a4nt_gumbel_bwd: bad arguments"); return A4NT_ERR_ARG; }
-    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, V, ds, ldd, y, ldy, stats, coef);
+    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(B), dim3(V >= 4096 ? 1024 : 256), 0, (hipStream_t)stream, V, ds, ldd, y, ldy, stats, coef);
     return a4nt_check_launch("gumbel_bwd");
 }
 
 // Fused log-softmax + NLL + backward seed.  target < 0: row ignored (loss 0, gradient 0).
 __global__ __launch_bounds__(256) void nll_rows_kernel(int V, float* logits, int ld, const long long* target,
                                                        float gscale, float* loss_rows, int write_grad) {
-    __shared__ float red[4];
-    const int r = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[ROWS_MAXW];
+    const int r = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     float* x = logits + (long long)r * ld;
     const long long tg = target[r];
     if (tg < 0) {
-        if (write_grad) for (int v = tid; v < V; v += 256) x[v] = 0.f;
+        if (write_grad) for (int v = tid; v < V; v += NT) x[v] = 0.f;
         if (tid == 0) loss_rows[r] = 0.f;
         return;
     }
     float m = -INFINITY;
-    for (int v = tid; v < V; v += 256) m = fmaxf(m, x[v]);
+    for (int v = tid; v < V; v += NT) m = fmaxf(m, x[v]);
     m = block_max(m, red);
     float s = 0.f;
-    for (int v = tid; v < V; v += 256) s += expf(x[v] - m);
+    for (int v = tid; v < V; v += NT) s += expf(x[v] - m);
     s = block_sum(s, red);
     const float lse = m + logf(s);
     if (tid == 0) loss_rows[r] = lse - x[tg];
     if (write_grad) {
         __syncthreads();
         const float inv = 1.0f / s;
-        for (int v = tid; v < V; v += 256) {
+        for (int v = tid; v < V; v += NT) {
             const float p = expf(x[v] - m) * inv;
             x[v] = (p - ((long long)v == tg ? 1.f : 0.f)) * gscale;
         }

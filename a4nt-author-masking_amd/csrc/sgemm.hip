@@ -13,6 +13,12 @@
 #include "common.h"
 
 #define BK 16
+#ifndef PFB
+#define PFB 2   // K tiles in flight, 128x128 tiles
+#endif
+#ifndef PFS
+#define PFS 4   // K tiles in flight, 64x64 tiles (small-M decode GEMMs are latency bound)
+#endif
 #define LPAD 4
 
 struct GemmArgs {
@@ -25,31 +31,58 @@ struct GemmArgs {
     int tiles_n;
 };
 
+// Operand staging uses raw buffer loads: out-of-range lanes get an out-of-bounds offset and the
+// hardware returns 0, so the loads are branch-free and stay in flight across the MFMA block (a
+// per-lane `if (in range) load` makes hipcc wait vmcnt(0) at every merge point, which serialised the
+// k-loop on L2 latency).  The descriptor is rebuilt per tile at the tile origin, so 32-bit offsets
+// are enough for any matrix size.  Rows need only 4-byte alignment (gfx950 runs in unaligned
+// access mode; dwordx4 loads of V = 10001-strided rows are legal).
+#define OOB 0x80000000u
+
+__device__ __forceinline__ f32x4 bl4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    f32x4 f;
+    f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+    return f;
+}
+__device__ __forceinline__ float bl1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ unsigned clamp_bytes(long long b) {
+    return (unsigned)(b < 0 ? 0 : (b > 0x7fffffffll ? 0x7fffffffll : b));
+}
+
 // Stage one [ROWS x BK] operand tile, global element (r, k) at base[r*ld + k]  ("k contiguous").
 template <int ROWS>
 struct StageKC {
     static constexpr int NV = ROWS / 64;
     f32x4 v[NV];
-    __device__ __forceinline__ void load(const float* base, int ld, int r0, int rmax, int k0, int kmax, bool aligned) {
+    // EDGE=false: the tile's BK columns are all valid (or the whole tile is past the end: kleft <= 0 -> zeros)
+    // EDGE=true : only kleft < BK columns are valid (last, partial K tile): per-element dword loads
+    template <bool EDGE>
+    __device__ __forceinline__ void load(const float* base, int ld, int r0, int rmax, int k0, int kmax) {
         const int tid = threadIdx.x;
         const int kq = (tid & 3) * 4;
+        const int nrows = min(ROWS, rmax - r0);
+        const int kleft = kmax - k0;
+        const float* origin = base + (long long)r0 * ld + k0;
+        const long long bytes = kleft > 0 ? ((long long)(nrows - 1) * ld + min(kleft, BK)) * 4 : 0;
+        __amdgpu_buffer_rsrc_t rs = make_rsrc(origin, clamp_bytes(bytes));
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
-            const int r = r0 + (tid >> 2) + 64 * p;
-            const int k = k0 + kq;
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (r < rmax) {
-                const float* src = base + (long long)r * ld + k;
-                if (aligned && k + 3 < kmax) {
-                    t = *reinterpret_cast<const f32x4*>(src);
-                } else {
-                    if (k + 0 < kmax) t.x = src[0];
-                    if (k + 1 < kmax) t.y = src[1];
-                    if (k + 2 < kmax) t.z = src[2];
-                    if (k + 3 < kmax) t.w = src[3];
-                }
+            const int r = (tid >> 2) + 64 * p;
+            const unsigned off = (unsigned)(r * ld + kq) * 4u;
+            const bool rv = r < nrows;
+            if (!EDGE) {
+                v[p] = bl4(rs, rv ? off : OOB);
+            } else {
+                f32x4 t;
+                t.x = bl1(rs, (rv && kq + 0 < kleft) ? off : OOB);
+                t.y = bl1(rs, (rv && kq + 1 < kleft) ? off + 4 : OOB);
+                t.z = bl1(rs, (rv && kq + 2 < kleft) ? off + 8 : OOB);
+                t.w = bl1(rs, (rv && kq + 3 < kleft) ? off + 12 : OOB);
+                v[p] = t;
             }
-            v[p] = t;
         }
     }
     __device__ __forceinline__ void store(float* S /* [BK][ROWS+LPAD] */) const {
@@ -72,26 +105,32 @@ struct StageMC {
     static constexpr int PER_ROW = COLS / 4;
     static constexpr int NV = (BK * PER_ROW) / 256;
     f32x4 v[NV];
-    __device__ __forceinline__ void load(const float* base, int ld, int c0, int cmax, int k0, int kmax, bool aligned) {
+    // EDGE=false: all COLS columns valid; EDGE=true: only cleft < COLS columns (last tile column / row block)
+    template <bool EDGE>
+    __device__ __forceinline__ void load(const float* base, int ld, int c0, int cmax, int k0, int kmax) {
         const int tid = threadIdx.x;
+        const int nk = min(BK, kmax - k0);
+        const int cleft = cmax - c0;
+        const float* origin = base + (long long)k0 * ld + c0;
+        const long long bytes = nk > 0 ? ((long long)(nk - 1) * ld + min(cleft, COLS)) * 4 : 0;
+        __amdgpu_buffer_rsrc_t rs = make_rsrc(origin, clamp_bytes(bytes));
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int idx = tid + 256 * p;
-            const int k = k0 + idx / PER_ROW;
-            const int c = c0 + (idx % PER_ROW) * 4;
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (k < kmax) {
-                const float* src = base + (long long)k * ld + c;
-                if (aligned && c + 3 < cmax) {
-                    t = *reinterpret_cast<const f32x4*>(src);
-                } else {
-                    if (c + 0 < cmax) t.x = src[0];
-                    if (c + 1 < cmax) t.y = src[1];
-                    if (c + 2 < cmax) t.z = src[2];
-                    if (c + 3 < cmax) t.w = src[3];
-                }
+            const int k = idx / PER_ROW;
+            const int c = (idx % PER_ROW) * 4;
+            const unsigned off = (unsigned)(k * ld + c) * 4u;
+            const bool kv = k < nk;
+            if (!EDGE) {
+                v[p] = bl4(rs, kv ? off : OOB);
+            } else {
+                f32x4 t;
+                t.x = bl1(rs, (kv && c + 0 < cleft) ? off : OOB);
+                t.y = bl1(rs, (kv && c + 1 < cleft) ? off + 4 : OOB);
+                t.z = bl1(rs, (kv && c + 2 < cleft) ? off + 8 : OOB);
+                t.w = bl1(rs, (kv && c + 3 < cleft) ? off + 12 : OOB);
+                v[p] = t;
             }
-            v[p] = t;
         }
     }
     __device__ __forceinline__ void store(float* S /* [BK][COLS+LPAD] */) const {
@@ -106,7 +145,76 @@ struct StageMC {
     }
 };
 
-template <bool TA, bool TB, int WM, int WN>
+template <bool T, int R> struct StageSel { typedef StageKC<R> type; };
+template <int R> struct StageSel<true, R> { typedef StageMC<R> type; };
+
+template <int WM, int WN>
+__device__ __forceinline__ void mma_tile(const float* as, const float* bs, int lane, int wm, int wn, f32x16 (&acc)[WM][WN]) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+        const int kr = kk + (lane >> 5);
+        float a[WM], b[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = as[kr * (BM + LPAD) + wm + 32 * i + (lane & 31)];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[j] = bs[kr * (BN + LPAD) + wn + 32 * j + (lane & 31)];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// K loop.  EA / EB: the "mn contiguous" operand of this workgroup is an edge tile (dword loads).
+// Full K tiles run through a PF-deep register ring with branch-free loads (tiles past the end load
+// zeros); a partial last K tile is staged synchronously afterwards.
+template <bool TA, bool TB, int WM, int WN, int PF, bool EA, bool EB>
+__device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kbeg, int kend, float (*As)[BK * (64 * WM + LPAD)],
+                                       float (*Bs)[BK * (64 * WN + LPAD)], int lane, int wm, int wn,
+                                       f32x16 (&acc)[WM][WN]) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    typename StageSel<TA, BM>::type sa[PF];      // TA: A stored [K][M] -> mn contiguous
+    typename StageSel<!TB, BN>::type sb[PF];     // !TB: B stored [K][N] -> mn contiguous
+    const int nk = (kend - kbeg) / BK;           // full tiles
+    const int kfull = kbeg + nk * BK;            // ring loads see [kbeg, kfull): anything later reads as zeros
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        sa[u].template load<TA && EA>(g.A, g.lda, m0, g.M, kbeg + u * BK, kfull);
+        sb[u].template load<!TB && EB>(g.B, g.ldb, n0, g.N, kbeg + u * BK, kfull);
+    }
+    if (nk > 0) {
+        sa[0].store(As[0]);
+        sb[0].store(Bs[0]);
+    }
+    __syncthreads();
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= nk) break;
+            const int cur = kt & 1;
+            // slot u is free (tile kt already sits in LDS): refill it with tile kt+PF
+            sa[u].template load<TA && EA>(g.A, g.lda, m0, g.M, kbeg + (kt + PF) * BK, kfull);
+            sb[u].template load<!TB && EB>(g.B, g.ldb, n0, g.N, kbeg + (kt + PF) * BK, kfull);
+            mma_tile<WM, WN>(As[cur], Bs[cur], lane, wm, wn, acc);
+            sa[(u + 1) % PF].store(As[cur ^ 1]);       // tile kt+1 (zeros when past the end)
+            sb[(u + 1) % PF].store(Bs[cur ^ 1]);
+            __syncthreads();
+        }
+    }
+    if (kfull < kend) {                                 // partial last K tile
+        sa[0].template load<true>(g.A, g.lda, m0, g.M, kfull, kend);
+        sb[0].template load<true>(g.B, g.ldb, n0, g.N, kfull, kend);
+        sa[0].store(As[0]);
+        sb[0].store(Bs[0]);
+        __syncthreads();
+        mma_tile<WM, WN>(As[0], Bs[0], lane, wm, wn, acc);
+    }
+}
+
+template <bool TA, bool TB, int WM, int WN, int PF>
 __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     __shared__ __attribute__((aligned(16))) float As[2][BK * (BM + LPAD)];
@@ -122,12 +230,6 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
 
-    const bool a_al = ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((g.lda & 3) == 0);
-    const bool b_al = ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && ((g.ldb & 3) == 0);
-
-    typename std::conditional<TA, StageMC<BM>, StageKC<BM>>::type sa;
-    typename std::conditional<TB, StageKC<BN>, StageMC<BN>>::type sb;
-
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -136,43 +238,13 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
-        sa.load(g.A, g.lda, m0, g.M, kbeg, kend, a_al);
-        sb.load(g.B, g.ldb, n0, g.N, kbeg, kend, b_al);
-        sa.store(As[0]);
-        sb.store(Bs[0]);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            sa.load(g.A, g.lda, m0, g.M, k0, kend, a_al);
-            sb.load(g.B, g.ldb, n0, g.N, k0, kend, b_al);
-        }
-        const float* as = As[cur];
-        const float* bs = Bs[cur];
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int kr = kk + (lane >> 5);
-            float a[WM], b[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = as[kr * (BM + LPAD) + wm + 32 * i + (lane & 31)];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = bs[kr * (BN + LPAD) + wn + 32 * j + (lane & 31)];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            sa.store(As[cur ^ 1]);
-            sb.store(Bs[cur ^ 1]);
-        }
-        __syncthreads();
-    }
+    // workgroup-uniform edge flags of the "mn contiguous" operands (K-contiguous ones need none)
+    const bool ea = TA && (g.M - m0 < BM);
+    const bool eb = !TB && (g.N - n0 < BN);
+    if (!ea && !eb) k_loop<TA, TB, WM, WN, PF, false, false>(g, m0, n0, kbeg, kend, As, Bs, lane, wm, wn, acc);
+    else if (ea && !eb) k_loop<TA, TB, WM, WN, PF, true, false>(g, m0, n0, kbeg, kend, As, Bs, lane, wm, wn, acc);
+    else if (!ea && eb) k_loop<TA, TB, WM, WN, PF, false, true>(g, m0, n0, kbeg, kend, As, Bs, lane, wm, wn, acc);
+    else k_loop<TA, TB, WM, WN, PF, true, true>(g, m0, n0, kbeg, kend, As, Bs, lane, wm, wn, acc);
 
     // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const bool add_bias = (g.bias != nullptr) && (blockIdx.z == 0);
@@ -196,13 +268,13 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
         }
 }
 
-template <bool TA, bool TB, int WM, int WN>
+template <bool TA, bool TB, int WM, int WN, int PF>
 static int launch_sgemm(GemmArgs g, int ksplit, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     dim3 grid(tiles_m * g.tiles_n, 1, ksplit);
-    hipLaunchKernelGGL((sgemm_kernel<TA, TB, WM, WN>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((sgemm_kernel<TA, TB, WM, WN, PF>), grid, dim3(256), 0, s, g);
     return a4nt_check_launch("sgemm");
 }
 
@@ -232,7 +304,7 @@ extern "C" int a4nt_sgemm(int transA, int transB, int M, int N, int K, const flo
     // tile choice: big 128x128 tiles when they still fill the chip, 64x64 otherwise
     const long long big_tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * ksplit;
     const bool big = big_tiles >= 200;
-    if (!transA && !transB) return big ? launch_sgemm<false, false, 2, 2>(g, ksplit, s) : launch_sgemm<false, false, 1, 1>(g, ksplit, s);
-    if (!transA && transB) return big ? launch_sgemm<false, true, 2, 2>(g, ksplit, s) : launch_sgemm<false, true, 1, 1>(g, ksplit, s);
-    return big ? launch_sgemm<true, false, 2, 2>(g, ksplit, s) : launch_sgemm<true, false, 1, 1>(g, ksplit, s);
+    if (!transA && !transB) return big ? launch_sgemm<false, false, 2, 2, PFB>(g, ksplit, s) : launch_sgemm<false, false, 1, 1, PFS>(g, ksplit, s);
+    if (!transA && transB) return big ? launch_sgemm<false, true, 2, 2, PFB>(g, ksplit, s) : launch_sgemm<false, true, 1, 1, PFS>(g, ksplit, s);
+    return big ? launch_sgemm<true, false, 2, 2, PFB>(g, ksplit, s) : launch_sgemm<true, false, 1, 1, PFS>(g, ksplit, s);
 }

@@ -171,7 +171,7 @@ class _GenDecode(Function):
         val_out = torch.zeros((n_max, B), device=dev)
         gen_lens = torch.zeros(B, dtype=torch.int32, device=dev)
         done = torch.zeros(B, dtype=torch.uint8, device=dev)
-        logits = torch.empty((B, V), device=dev)
+        logits = ops.padded_rows(B, V, dev)
         ones = torch.ones(B, device=dev)
         tok0 = tok0.contiguous()
         s = ops._s()
@@ -224,8 +224,8 @@ class _GenDecode(Function):
         V, E = emb_W.shape
         s = ops._s()
         # d(sample) from every consumer, contracted over its embedding matrix, time-batched
-        S = torch.empty((n, B, V), device=dev)
-        S2 = S.view(n * B, V)
+        S2 = ops.padded_rows(n * B, V, dev)             # rows 16-byte aligned for the time-batched GEMMs
+        S = S2.unflatten(0, (n, B))
         first = True
         for demb, W in handle.contribs:
             gemm(demb[:n].reshape(n * B, -1), W, transB=True, out=S2, beta=0 if first else 1)

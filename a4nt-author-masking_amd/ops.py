@@ -96,6 +96,12 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, beta=0, ksplit=1
     return out
 
 
+def padded_rows(N, V, device, lead=()):
+    """[*lead, N, V] fp32 view whose rows start 16-byte aligned (leading dimension rounded up to 16)."""
+    Vp = (V + 15) // 16 * 16
+    return torch.empty(tuple(lead) + (N, Vp), device=device, dtype=torch.float32)[..., :V]
+
+
 def slab_reduce(slabs, c0=0, ncols=None, add=None):
     """sum over the leading (split-K) axis of slabs[S,R,C_total][:, :, c0:c0+ncols] (+ add)."""
     lib = _lib.load()
@@ -357,9 +363,10 @@ class _ProjNLL(Function):
     def forward(ctx, h, W, b, target, n_valid):
         lib = _lib.load()
         N, V = h.shape[0], W.shape[1]
-        logits = gemm(h, W, bias=b)
+        logits = padded_rows(N, V, h.device)          # 16-byte aligned rows: vector loads in the backward GEMMs
+        gemm(h, W, bias=b, out=logits)
         loss_rows = torch.empty(N, device=h.device, dtype=torch.float32)
-        check(lib.a4nt_nll_rows(N, V, _p(logits), V, _p(target), 1.0 / float(n_valid), _p(loss_rows), 1, _s()),
+        check(lib.a4nt_nll_rows(N, V, _p(logits), _ld(logits), _p(target), 1.0 / float(n_valid), _p(loss_rows), 1, _s()),
               'a4nt_nll_rows')
         ctx.save_for_backward(h, W, logits)
         return loss_rows.sum() / float(n_valid)

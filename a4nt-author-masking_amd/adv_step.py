@@ -18,9 +18,14 @@ from .gen_decode import SoftSamples
 
 
 def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all', maxlen=100, auths=None,
-                     cycle_compute=False, append_symb=None, temp=0.5, cycle_loss_type='ml', targs=None):
+                     cycle_compute=False, append_symb=None, temp=0.5, cycle_loss_type='ml', targs=None,
+                     real_batch=None):
     """Returns (eval_logits [B,C] in input order, enc_out, samples (SoftSamples, generation order), gen_lens,
-    char_outs[, cycle loss])."""
+    char_outs[, cycle loss][, (real logits, real enc_out)]).
+
+    real_batch = (ids, lens): also classify a batch of real sentences; when the classifier offers
+    forward_classify_multi the generated and the real batch share one pass (train_adversarial_translator.py
+    :448 and :463 are two separate forward_classify calls in the reference; rows are independent)."""
     if backprop_for in ('eval', 'None'):
         modelGen.eval()
     else:
@@ -36,8 +41,15 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
     samples_srt = samples.index_select_batch(sort_dev)
     if backprop_for == 'eval':
         samples_srt = samples_srt.detach()
-    eval_out = modelEval.forward_classify(samples_srt, adv_inp=True, lens=len_sorted.tolist(),
-                                          drop=(backprop_for == 'eval'))
+    drop = backprop_for == 'eval'
+    real_out = None
+    if real_batch is not None and hasattr(modelEval, 'forward_classify_multi'):
+        eval_out, real_out = modelEval.forward_classify_multi(
+            [(samples_srt, len_sorted.tolist(), True), (real_batch[0], real_batch[1], False)], drop=drop)
+    else:
+        eval_out = modelEval.forward_classify(samples_srt, adv_inp=True, lens=len_sorted.tolist(), drop=drop)
+        if real_batch is not None:
+            real_out = modelEval.forward_classify(real_batch[0], lens=real_batch[1])
     logits = eval_out[0].index_select(0, rev_dev)
     out = (logits, eval_out[1], samples, gen_lens, char_outs)
     if cycle_compute and backprop_for != 'eval':
@@ -48,6 +60,8 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
         cyc = modelGen.forward_mltrain_loss(reverse_inp, len_sorted.tolist(), inps, lens, targs, auths=auths,
                                             adv_inp=True, sort_enc=rev_dev)
         out = out + (cyc,)
+    if real_batch is not None:
+        out = out + (real_out,)
     return out
 
 
@@ -131,10 +145,10 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
     _set_requires_grad(modelEval, True)
     _set_requires_grad(modelGen, False)
     inps, targs, auths, lens = src_batch
-    outs = adv_forward_pass(modelGen, modelEval, inps, lens, end_c=end_c, backprop_for='eval', maxlen=maxlen,
-                            auths=auths, temp=temp)
     _, gt_targs, _, gt_lens = tgt_batch
-    eval_out_gt = modelEval.forward_classify(gt_targs, lens=gt_lens)
+    outs = adv_forward_pass(modelGen, modelEval, inps, lens, end_c=end_c, backprop_for='eval', maxlen=maxlen,
+                            auths=auths, temp=temp, real_batch=(gt_targs, gt_lens))
+    eval_out_gt = outs[-1]
     optimEval.zero_grad()
     targ_aid = 1 - c_aid
     real_aid_out = eval_out_gt[0][:, targ_aid]

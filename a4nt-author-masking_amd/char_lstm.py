@@ -67,33 +67,62 @@ class CharLstm(nn.Module):
     forward_eval = forward
     forward_gen = forward
 
+    def _embed_any(self, x, adv_inp, drop, dev):
+        T, B = x.shape[0], x.shape[1]
+        if isinstance(x, SoftSamples):
+            emb = sample_embed(x, self.encoder.weight)
+        elif adv_inp:
+            emb = ops.linear_kn(x.reshape(T * B, -1), self.encoder.weight).view(T, B, -1)
+        else:
+            emb = ops.embedding(x.to(dev), self.encoder.weight, 0)
+        return self._drop(emb, self.p_enc, drop)
+
+    def _classify_emb(self, emb, lens, h_prev, compute_softmax, drop):
+        dev = emb.device
+        T, B = emb.shape[0], emb.shape[1]
+        lens_dev = lens_to_device(lens, T, dev)
+        rnn_out, hidden = run_stack(self.rec_layers, emb, lens_dev, self.num_rec_layers, self.en_residual, h_prev)
+        t_eff = max(int(l) for l in lens) if lens is not None else T
+        if self.max_pool_rnn == 1:
+            ctxt = torch.cat([packed_mean(rnn_out, lens, T), hidden[0][-1]], dim=-1)
+        elif self.max_pool_rnn == 2:
+            ctxt = rnn_out[:t_eff].max(dim=0)[0]          # zero pads take part (char_lstm.py:303-306)
+        elif self.max_pool_rnn == 3:
+            ctxt = torch.cat([rnn_out[:t_eff].max(dim=0)[0],
+                              hidden[0].transpose(0, 1).contiguous().view(B, -1)], dim=-1)
+        else:
+            ctxt = hidden[0][-1]
+        enc_out = self._drop(ctxt, self.p_dec, drop)
+        dec_out = ops.linear_kn(enc_out, self.decoder_W, self.decoder_b)
+        if compute_softmax:
+            dec_out = F.softmax(dec_out, dim=-1)
+        return dec_out, enc_out
+
     def forward_classify(self, x, h_prev=None, compute_softmax=False, predict_mode=False, adv_inp=False, lens=None,
                          drop=True):
         dev = self.decoder_W.device
-        T, B = x.shape[0], x.shape[1]
         ctxmgr = torch.no_grad() if predict_mode else torch.enable_grad()
         with ctxmgr:
-            if isinstance(x, SoftSamples):
-                emb = sample_embed(x, self.encoder.weight)
-            elif adv_inp:
-                emb = ops.linear_kn(x.reshape(T * B, -1), self.encoder.weight).view(T, B, -1)
-            else:
-                emb = ops.embedding(x.to(dev), self.encoder.weight, 0)
-            emb = self._drop(emb, self.p_enc, drop)
-            lens_dev = lens_to_device(lens, T, dev)
-            rnn_out, hidden = run_stack(self.rec_layers, emb, lens_dev, self.num_rec_layers, self.en_residual, h_prev)
-            t_eff = max(int(l) for l in lens) if lens is not None else T
-            if self.max_pool_rnn == 1:
-                ctxt = torch.cat([packed_mean(rnn_out, lens, T), hidden[0][-1]], dim=-1)
-            elif self.max_pool_rnn == 2:
-                ctxt = rnn_out[:t_eff].max(dim=0)[0]          # zero pads take part (char_lstm.py:303-306)
-            elif self.max_pool_rnn == 3:
-                ctxt = torch.cat([rnn_out[:t_eff].max(dim=0)[0],
-                                  hidden[0].transpose(0, 1).contiguous().view(B, -1)], dim=-1)
-            else:
-                ctxt = hidden[0][-1]
-            enc_out = self._drop(ctxt, self.p_dec, drop)
-            dec_out = ops.linear_kn(enc_out, self.decoder_W, self.decoder_b)
-            if compute_softmax:
-                dec_out = F.softmax(dec_out, dim=-1)
-        return dec_out, enc_out
+            emb = self._embed_any(x, adv_inp, drop, dev)
+            return self._classify_emb(emb, lens, h_prev, compute_softmax, drop)
+
+    def forward_classify_multi(self, inputs, drop=True):
+        """Several independent forward_classify calls as ONE pass: the batches are concatenated
+        along the batch axis so that each persistent LSTM sweep serves all of them (twice the rows per
+        inter-workgroup synchronisation).  `inputs` = [(x, lens, adv_inp), ...]; rows are independent, so
+        every result equals the separate call's.  Pooling variants that look at the padded length
+        (maxpoolrnn 2/3) fall back to separate calls."""
+        dev = self.decoder_W.device
+        if self.max_pool_rnn in (2, 3) or len(inputs) == 1:
+            return [self.forward_classify(x, adv_inp=a, lens=l, drop=drop) for x, l, a in inputs]
+        embs, lens_all, sizes = [], [], []
+        T = max(x.shape[0] for x, _, _ in inputs)
+        for x, lens, adv in inputs:
+            e = self._embed_any(x, adv, drop, dev)
+            if e.shape[0] < T:
+                e = F.pad(e, (0, 0, 0, 0, 0, T - e.shape[0]))
+            embs.append(e)
+            lens_all += [int(l) for l in (lens if lens is not None else [x.shape[0]] * x.shape[1])]
+            sizes.append(x.shape[1])
+        dec_out, enc_out = self._classify_emb(torch.cat(embs, dim=1), lens_all, None, False, drop)
+        return list(zip(dec_out.split(sizes, dim=0), enc_out.split(sizes, dim=0)))

@@ -114,10 +114,15 @@ def slab_reduce(slabs, c0=0, ncols=None, add=None):
 
 
 def _auto_ksplit(M, N, K):
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    if tiles >= 192 or K < 1024:
+    """Split K when the 128x128 tiling would leave most of the 256 CUs idle (a4nt_sgemm picks the
+    128x128 kernel once tiles*ksplit >= 200, the latency-tolerant 64x64 one otherwise)."""
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if t128 >= 160 or K < 1024:
         return 1
-    return int(max(1, min(256 // tiles, K // 256, 32)))
+    t64 = ((M + 63) // 64) * ((N + 63) // 64)
+    if t128 >= 32:                       # enough big tiles: aim for ~256-512 of them
+        return int(max(1, min((256 + t128 - 1) // t128, K // 512, 32)))
+    return int(max(1, min(512 // max(t64, 1), K // 256, 32)))
 
 
 def gemm_auto(A, B, transA=False, transB=False, bias=None):

@@ -7,7 +7,8 @@ import os
 from ctypes import c_int, c_uint, c_float, c_longlong, c_ulonglong, c_void_p, c_char_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liba4nt_hip.so')
+# A4NT_HIP_LIB: diagnostic builds only (tools/lstm_stamp.py loads the phase-stamp variant)
+LIB_PATH = os.environ.get('A4NT_HIP_LIB') or os.path.join(_HERE, 'liba4nt_hip.so')
 
 P = c_void_p
 _SIGS = {
@@ -17,13 +18,14 @@ _SIGS = {
     'a4nt_sgemm': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int,
                            c_longlong, P]),
     'a4nt_lstm_geometry': (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'a4nt_lstm_set_max_workgroups': (c_int, [c_int]),
     'a4nt_lstm_xch_floats': (c_longlong, [c_int, c_int, c_int]),
     'a4nt_lstm_sync_words': (c_int, [c_int, c_int]),
     'a4nt_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'a4nt_lstm_seq_bwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'a4nt_lstm_check_timeout': (c_int, [P, c_int, P]),
     'a4nt_lstm_dec_step': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
-    'a4nt_lstm_cell_bwd': (c_int, [c_int, c_int, P, P, P, P, P, P, P, P]),
+    'a4nt_lstm_cell_bwd': (c_int, [c_int, c_int, P, P, P, P, c_int, c_longlong, P, c_int, P, P, P]),
     'a4nt_gumbel_fwd': (c_int, [c_int, c_int, P, c_int, P, c_int, c_ulonglong, c_uint, c_float, c_float, c_int, c_int,
                                 P, c_int, P, P, P, P, P, P, c_longlong, P, c_int, P]),
     'a4nt_gumbel_bwd': (c_int, [c_int, c_int, P, c_int, P, c_int, P, c_float, P]),

@@ -22,6 +22,22 @@
 // once t >= len[row]; no sorting or packing is needed by the kernels.
 #include "common.h"
 
+// Diagnostic build only (-DA4NT_STAMP, tools/lstm_stamp.py): per-phase s_memtime sums of workgroup 0,
+// written to spare words of the sync block that no kernel code reads.  Never defined in the product.
+#ifdef A4NT_STAMP
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = 0;
+#define STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[k] += n_ - st_prev; st_prev = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_FLUSH(sync, G) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long* d_ = (unsigned long long*)((sync) + 32 * (G) + 8); for (int k_ = 0; k_ < 8; ++k_) d_[k_] = st_acc[k_]; } } while (0)
+#define STAMP_WAITV() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN()
+#define STAMP(k)
+#define STAMP_FLUSH(sync, G)
+#define STAMP_WAITV()
+#endif
+
 #define PSTR 68   // LDS row stride (floats) of the partial gate tiles: conflict-free MFMA-layout stores
 
 struct LstmFwdArgs {
@@ -45,7 +61,7 @@ struct LstmFwdArgs {
     int step0;              // decode: absolute step index (selects the exchange parity)
 };
 
-template <int MT>
+template <int MT, int NJ>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float part[4][MT][16 * PSTR];
     __shared__ __attribute__((aligned(16))) float hstage[MT][256];
@@ -54,23 +70,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
     const int g = blockIdx.x % a.G, j = blockIdx.x / a.G;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H = a.H, H4 = 4 * a.H;
-    const int nj = H >> 6;                 // 16-wide k blocks in this wave's K quarter
+    constexpr int nj = NJ;                 // 16-wide k blocks in this wave's K quarter (H = 64*NJ)
     const int u0 = 16 * j;
     const int r0 = g * 16 * MT;
     const int fr = lane & 15, fq = lane >> 4;      // MFMA fragment row/col and k-quad
     const int crow = tid >> 4, cunit = tid & 15;   // cell-update (row, unit) of this thread
 
     // ---- recurrent weights -> registers --------------------------------------------------
-    f32x4 wreg[8][4];
+    f32x4 wreg[NJ][4];
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj)
+    for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-        for (int gt = 0; gt < 4; ++gt) {
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (jj < nj)
-                t = *reinterpret_cast<const f32x4*>(a.whh + (long long)(gt * H + u0 + fr) * H + w * (H >> 2) + 16 * jj + 4 * fq);
-            wreg[jj][gt] = t;
-        }
+        for (int gt = 0; gt < 4; ++gt)
+            wreg[jj][gt] = *reinterpret_cast<const f32x4*>(a.whh + (long long)(gt * H + u0 + fr) * H + w * (H >> 2) + 16 * jj + 4 * fq);
 
     unsigned* ctr = a.sync + 32 * g;
     unsigned* tmo = a.sync + 32 * a.G;
@@ -127,8 +139,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
         par_r = a.step0 & 1;
     }
 
+    STAMP_DECL
     for (int t = 0; t < Tg; ++t) {
         const int par_w = par_r ^ 1;
+        STAMP_BEGIN();
         // (a) input gates of this step for the cell-update threads (independent of h: issue early)
         float xg[MT][4];
 #pragma unroll
@@ -156,35 +170,32 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
             __syncthreads();
             if (!s_ok) break;
         }
+        STAMP(0);
         // (c)+(d) A fragments straight from the exchange buffer, recurrent MFMA
         f32x4 acc[4][MT];
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[gt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 af[8][MT];
+        f32x4 af[NJ][MT];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
+        for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                af[jj][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (jj < nj) {
-                    const long long blk = ((long long)(par_r * a.G + g) * a.NW + (w * nj + jj)) * MT + mt;
-                    af[jj][mt] = ld16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + fq * 4) * 4));
-                }
+                const long long blk = ((long long)(par_r * a.G + g) * a.NW + (w * nj + jj)) * MT + mt;
+                af[jj][mt] = ld16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + fq * 4) * 4));
             }
+        STAMP_WAITV();
+        STAMP(1);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            if (jj < nj) {
+        for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int gt = 0; gt < 4; ++gt)
+                for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[gt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[jj][mt][i], wreg[jj][gt][i], acc[gt][mt], 0, 0, 0);
-            }
-        }
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[gt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[jj][mt][i], wreg[jj][gt][i], acc[gt][mt], 0, 0, 0);
         // (e) partial gate tiles -> LDS   (C layout: col = lane&15, row = 4*(lane>>4) + reg)
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
@@ -192,11 +203,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) part[w][mt][(4 * fq + i) * PSTR + gt * 16 + fr] = acc[gt][mt][i];
+        STAMP(2);
         __syncthreads();
+        STAMP(3);
         // (f) cell update, one (row, unit) per thread and row tile
+        float o_i[MT], o_f[MT], o_g[MT], o_o[MT], o_c[MT], o_h[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int rb = r0 + 16 * mt + crow;
             float pre[4];
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt) {
@@ -208,29 +221,40 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
             const float hn = og * tanhf_(cn);
             const bool active = t < len_r[mt];
             if (active) { c_reg[mt] = cn; h_reg[mt] = hn; }
-            if (rb < a.B) {
-                const long long o = ((long long)t * a.B + rb);
-                a.hs[o * H + u0 + cunit] = active ? hn : 0.f;
-                if (a.gates) {
-                    float* pg = a.gates + o * H4 + u0 + cunit;
-                    pg[0] = ig; pg[H] = fg; pg[2 * H] = gg; pg[3 * H] = og;
-                }
-                if (a.cs) a.cs[o * H + u0 + cunit] = cn;
-            }
+            o_i[mt] = ig; o_f[mt] = fg; o_g[mt] = gg; o_o[mt] = og; o_c[mt] = cn; o_h[mt] = active ? hn : 0.f;
             hstage[mt][crow * 16 + cunit] = h_reg[mt];
         }
+        STAMP(4);
         __syncthreads();
-        // (g) publish this workgroup's h block(s) for step t+1
+        STAMP(5);
+        // (g) publish this workgroup's h block(s) for step t+1 FIRST (critical path of every peer) ...
         if (w < MT) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(&hstage[w][4 * lane]);
             const long long blk = ((long long)(par_w * a.G + g) * a.NW + j) * MT + w;
             st16_sc1(rs, (unsigned)(blk * blk_bytes + lane * 16), v);
             drain_vmem();
         }
+        STAMP(6);
         __syncthreads();
         if (a.mode == 0 && tid == 0) add_flag(ctr, 1u);
+        STAMP(7);
+        // ... then the outputs nobody waits for inside this launch (h_t, saved activations)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rb = r0 + 16 * mt + crow;
+            if (rb < a.B) {
+                const long long o = ((long long)t * a.B + rb);
+                a.hs[o * H + u0 + cunit] = o_h[mt];
+                if (a.gates) {
+                    float* pg = a.gates + o * H4 + u0 + cunit;
+                    pg[0] = o_i[mt]; pg[H] = o_f[mt]; pg[2 * H] = o_g[mt]; pg[3 * H] = o_o[mt];
+                }
+                if (a.cs) a.cs[o * H + u0 + cunit] = o_c[mt];
+            }
+        }
         par_r = par_w;
     }
+    STAMP_FLUSH(a.sync, a.G);
 
     // final states and zero tail of the outputs for groups that finished early
 #pragma unroll
@@ -263,7 +287,7 @@ struct LstmBwdArgs {
     int need_dh0;           // run the recurrent product of the last step too
 };
 
-template <int MT>
+template <int MT, int NJ>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float part[4][MT][16 * 20];
     __shared__ __attribute__((aligned(16))) float stage[4][MT][256];
@@ -272,21 +296,19 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
     const int g = blockIdx.x % a.G, j = blockIdx.x / a.G;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H = a.H, H4 = 4 * a.H;
-    const int njb = H >> 4;                 // 16-row k blocks per gate (<= 32)
+    constexpr int njb = 4 * NJ;             // 16-row k blocks per gate (H = 64*NJ)
     const int u0 = 16 * j;
     const int r0 = g * 16 * MT;
     const int fr = lane & 15, fq = lane >> 4;
     const int crow = tid >> 4, cunit = tid & 15;
 
     // wave w: rows [w*H, (w+1)*H) of W_hh (gate w), columns u0..u0+15
-    f32x4 wreg[32];
+    f32x4 wreg[njb];
 #pragma unroll
-    for (int jj = 0; jj < 32; ++jj) {
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (jj < njb) {
-            const float* p = a.whh + (long long)(w * H + 16 * jj + 4 * fq) * H + u0 + fr;
-            t.x = p[0]; t.y = p[H]; t.z = p[2 * H]; t.w = p[3 * H];
-        }
+    for (int jj = 0; jj < njb; ++jj) {
+        const float* p = a.whh + (long long)(w * H + 16 * jj + 4 * fq) * H + u0 + fr;
+        f32x4 t;
+        t.x = p[0]; t.y = p[H]; t.z = p[2 * H]; t.w = p[3 * H];
         wreg[jj] = t;
     }
 
@@ -328,6 +350,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
     int s = 0;   // published steps so far
     for (int t = Tg - 1; t >= 0; --t, ++s) {
         const int par = s & 1;
+        float dpo[MT][4];
         // (a) cell backward for this thread's (row, unit)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -357,13 +380,22 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
                     dp[3] = dh * tc * og * (1.f - og);
                     dc_next[mt] = dc * fg;
                 }
-                float* pd = a.dgates + o * H4 + u0 + cunit;
-                pd[0] = dp[0]; pd[H] = dp[1]; pd[2 * H] = dp[2]; pd[3 * H] = dp[3];
             }
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) stage[gt][mt][crow * 16 + cunit] = dp[gt];
+            for (int gt = 0; gt < 4; ++gt) { stage[gt][mt][crow * 16 + cunit] = dp[gt]; dpo[mt][gt] = dp[gt]; }
         }
-        if (t == 0 && !a.need_dh0) break;
+        if (t == 0 && !a.need_dh0) {
+            // last step: nothing to exchange, just emit dgates_0
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int rb = r0 + 16 * mt + crow;
+                if (rb < a.B) {
+                    float* pd = a.dgates + ((long long)rb) * H4 + u0 + cunit;
+                    pd[0] = dpo[mt][0]; pd[H] = dpo[mt][1]; pd[2 * H] = dpo[mt][2]; pd[3 * H] = dpo[mt][3];
+                }
+            }
+            break;
+        }
         __syncthreads();
         // (b) publish dgates_t: wave w writes the blocks of gate w
 #pragma unroll
@@ -374,41 +406,42 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
         }
         drain_vmem();
         __syncthreads();
-        if (tid == 0) {
-            add_flag(ctr, 1u);
-            s_ok = wait_ge(ctr, (unsigned)(a.NW * (s + 1)), tmo) ? 1 : 0;
+        if (tid == 0) add_flag(ctr, 1u);
+        // dgates_t for the time-batched weight-gradient GEMMs: nobody waits for it inside this launch
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rb = r0 + 16 * mt + crow;
+            if (rb < a.B) {
+                float* pd = a.dgates + ((long long)t * a.B + rb) * H4 + u0 + cunit;
+                pd[0] = dpo[mt][0]; pd[H] = dpo[mt][1]; pd[2 * H] = dpo[mt][2]; pd[3 * H] = dpo[mt][3];
+            }
         }
+        if (tid == 0) s_ok = wait_ge(ctr, (unsigned)(a.NW * (s + 1)), tmo) ? 1 : 0;
         __syncthreads();
         if (!s_ok) break;
         // (c) dh_rec[:, u0..u0+15] = dgates_t[:, gate w rows] * W_hh[gate w rows, u0..u0+15], K split over waves
         f32x4 acc[MT][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = acc[mt][0]; }
+        constexpr int CH = njb < 8 ? njb : 8;       // blocks loaded per chunk
 #pragma unroll
-        for (int jc = 0; jc < 4; ++jc) {
-            f32x4 af[8][MT];
+        for (int jc = 0; jc < njb / CH; ++jc) {
+            f32x4 af[CH][MT];
 #pragma unroll
-            for (int j8 = 0; j8 < 8; ++j8)
+            for (int j8 = 0; j8 < CH; ++j8)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int jj = jc * 8 + j8;
-                    af[j8][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (jj < njb) {
-                        const long long blk = ((((long long)par * a.G + g) * 4 + w) * a.NW + jj) * MT + mt;
-                        af[j8][mt] = ld16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + fq * 4) * 4));
-                    }
+                    const int jj = jc * CH + j8;
+                    const long long blk = ((((long long)par * a.G + g) * 4 + w) * a.NW + jj) * MT + mt;
+                    af[j8][mt] = ld16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + fq * 4) * 4));
                 }
 #pragma unroll
-            for (int j8 = 0; j8 < 8; ++j8) {
-                const int jj = jc * 8 + j8;
-                if (jj < njb) {
+            for (int j8 = 0; j8 < CH; ++j8)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[mt][j8 & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j8][mt][i], wreg[jj][i], acc[mt][j8 & 1], 0, 0, 0);
-                }
-            }
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][j8 & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j8][mt][i], wreg[jc * CH + j8][i], acc[mt][j8 & 1], 0, 0, 0);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -436,18 +469,45 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// Workgroup budget of one sweep.  256 = one workgroup per CU.  The MT = 1 kernels fit two per CU
+// (<= 224 VGPR+AGPR, 18 KB LDS), and with 512 co-resident workgroups two independent row groups
+// share every CU, so one group's hand-off latency hides behind the other's MFMA phase (B = 256,
+// H = 512: 6.7 us/step against 8.8 us/step for 256 workgroups of MT = 2).  Needs the GPU to
+// itself (all 512 resident); a4nt_lstm_set_max_workgroups(256) restores one workgroup per CU.
+static int g_max_wgs = 512;
+extern "C" int a4nt_lstm_set_max_workgroups(int n) {
+    if (n != 256 && n != 512) { a4nt_set_error("a4nt_lstm_set_max_workgroups: 256 or 512"); return A4NT_ERR_ARG; }
+    g_max_wgs = n;
+    return A4NT_OK;
+}
 static int pick_mt(int B, int NW, int* G) {
     for (int mt = 1; mt <= 4; mt *= 2) {
         const int g = (B + 16 * mt - 1) / (16 * mt);
-        if ((long long)g * NW <= 256) { *G = g; return mt; }
+        if ((long long)g * NW <= (mt == 1 ? g_max_wgs : 256)) { *G = g; return mt; }
     }
     return 0;
 }
 
-static bool bad_h(int H) { return H < 64 || H > 512 || (H & 63) != 0; }
+#define A4NT_DISPATCH_LSTM(KERNEL, mt, nj, grid, block, s, a)                                                   \
+    do {                                                                                                         \
+        if (mt == 1 && nj == 1) hipLaunchKernelGGL((KERNEL<1, 1>), grid, block, 0, s, a);                         \
+        else if (mt == 1 && nj == 2) hipLaunchKernelGGL((KERNEL<1, 2>), grid, block, 0, s, a);                    \
+        else if (mt == 1 && nj == 4) hipLaunchKernelGGL((KERNEL<1, 4>), grid, block, 0, s, a);                    \
+        else if (mt == 1 && nj == 8) hipLaunchKernelGGL((KERNEL<1, 8>), grid, block, 0, s, a);                    \
+        else if (mt == 2 && nj == 1) hipLaunchKernelGGL((KERNEL<2, 1>), grid, block, 0, s, a);                    \
+        else if (mt == 2 && nj == 2) hipLaunchKernelGGL((KERNEL<2, 2>), grid, block, 0, s, a);                    \
+        else if (mt == 2 && nj == 4) hipLaunchKernelGGL((KERNEL<2, 4>), grid, block, 0, s, a);                    \
+        else if (mt == 2 && nj == 8) hipLaunchKernelGGL((KERNEL<2, 8>), grid, block, 0, s, a);                    \
+        else if (mt == 4 && nj == 1) hipLaunchKernelGGL((KERNEL<4, 1>), grid, block, 0, s, a);                    \
+        else if (mt == 4 && nj == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, block, 0, s, a);                    \
+        else if (mt == 4 && nj == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, block, 0, s, a);                    \
+        else hipLaunchKernelGGL((KERNEL<4, 8>), grid, block, 0, s, a);                                            \
+    } while (0)
+
+static bool bad_h(int H) { return !(H == 64 || H == 128 || H == 256 || H == 512); }
 
 extern "C" int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out) {
-    if (B <= 0 || bad_h(H)) { a4nt_set_error("a4nt_lstm: H must be a multiple of 64 in [64,512], got H=%d B=%d", H, B); return A4NT_ERR_ARG; }
+    if (B <= 0 || bad_h(H)) { a4nt_set_error("a4nt_lstm: H must be 64, 128, 256 or 512 (multiple of 64 kernels are instantiated for these), got H=%d B=%d", H, B); return A4NT_ERR_ARG; }
     int G = 0;
     const int mt = pick_mt(B, H / 16, &G);
     if (!mt) { a4nt_set_error("a4nt_lstm: batch %d too large for one sweep at H=%d (max %d rows)", B, H, 64 * (256 / (H / 16))); return A4NT_ERR_ARG; }
@@ -488,9 +548,7 @@ extern "C" int a4nt_lstm_seq_fwd(int T, int B, int H, const float* gx, const flo
     a.cg = gc; a.ptab = nullptr; a.tok = nullptr; a.val = nullptr;
     a.hs = hs; a.gates = gates; a.cs = cs; a.hN = hN; a.cN = cN; a.hx = xch; a.sync = sync; a.mode = 0; a.step0 = 0;
     dim3 grid(G * a.NW), block(256);
-    if (mt == 1) hipLaunchKernelGGL(lstm_fwd_kernel<1>, grid, block, 0, s, a);
-    else if (mt == 2) hipLaunchKernelGGL(lstm_fwd_kernel<2>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(lstm_fwd_kernel<4>, grid, block, 0, s, a);
+    A4NT_DISPATCH_LSTM(lstm_fwd_kernel, mt, H / 64, grid, block, s, a);
     return a4nt_check_launch("lstm_seq_fwd");
 }
 
@@ -512,9 +570,7 @@ extern "C" int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const
     a.mode = 1; a.step0 = step;
     dim3 grid(G * a.NW), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (mt == 1) hipLaunchKernelGGL(lstm_fwd_kernel<1>, grid, block, 0, s, a);
-    else if (mt == 2) hipLaunchKernelGGL(lstm_fwd_kernel<2>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(lstm_fwd_kernel<4>, grid, block, 0, s, a);
+    A4NT_DISPATCH_LSTM(lstm_fwd_kernel, mt, H / 64, grid, block, s, a);
     return a4nt_check_launch("lstm_dec_step");
 }
 
@@ -537,8 +593,6 @@ extern "C" int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const fl
     a.dgates = dgates; a.dh0 = dh0; a.dc0 = dc0; a.gxch = xch; a.sync = sync;
     a.need_dh0 = (dh0 != nullptr) ? 1 : 0;
     dim3 grid(G * a.NW), block(256);
-    if (mt == 1) hipLaunchKernelGGL(lstm_bwd_kernel<1>, grid, block, 0, s, a);
-    else if (mt == 2) hipLaunchKernelGGL(lstm_bwd_kernel<2>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(lstm_bwd_kernel<4>, grid, block, 0, s, a);
+    A4NT_DISPATCH_LSTM(lstm_bwd_kernel, mt, H / 64, grid, block, s, a);
     return a4nt_check_launch("lstm_seq_bwd");
 }

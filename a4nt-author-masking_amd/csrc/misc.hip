@@ -98,17 +98,18 @@ extern "C" int a4nt_slab_reduce(int S, long long stride, int R, int C, const flo
 }
 
 // Element-wise LSTM cell backward of one decoder step:
-//   dh = dh_a + dh_b ; dc = dc_io + dh*o*(1-tanh(c)^2) ; dgates (pre-activation) ; dc_io = dc*f
+//   dh = sum_s dh_slabs[s] (split-K partials of dlogits*W^T) + dh_b ; dc = dc_io + dh*o*(1-tanh(c)^2) ;
+//   dgates (pre-activation) ; dc_io = dc*f
 __global__ void lstm_cell_bwd_kernel(int B, int H, const float* gates, const float* c_t, const float* c_prev,
-                                     const float* dh_a, const float* dh_b, float* dc_io, float* dgates) {
+                                     const float* dh_slabs, int n_slabs, long long slab_stride, const float* dh_b,
+                                     int ldb, float* dc_io, float* dgates) {
     const long long total = (long long)B * H;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int b = (int)(i / H), u = (int)(i - (long long)b * H);
         const float* pg = gates + (long long)b * 4 * H + u;
         const float ig = pg[0], fg = pg[H], gg = pg[2 * H], og = pg[3 * H];
-        float dh = 0.f;
-        if (dh_a) dh += dh_a[i];
-        if (dh_b) dh += dh_b[i];
+        float dh = dh_b ? dh_b[(long long)b * ldb + u] : 0.f;
+        for (int s = 0; s < n_slabs; ++s) dh += dh_slabs[s * slab_stride + i];
         const float tc = tanhf_(c_t[i]);
         const float cp = c_prev ? c_prev[i] : 0.f;
         const float dc = dc_io[i] + dh * og * (1.f - tc * tc);
@@ -121,13 +122,14 @@ __global__ void lstm_cell_bwd_kernel(int B, int H, const float* gates, const flo
     }
 }
 extern "C" int a4nt_lstm_cell_bwd(int B, int H, const float* gates, const float* c_t, const float* c_prev,
-                                  const float* dh_a, const float* dh_b, float* dc_io, float* dgates, void* stream) {
+                                  const float* dh_slabs, int n_slabs, long long slab_stride, const float* dh_b, int ldb,
+                                  float* dc_io, float* dgates, void* stream) {
     if (B <= 0 || H <= 0) return A4NT_OK;
-    if (!gates || !c_t || !dc_io || !dgates) { a4nt_set_error("a4nt_lstm_cell_bwd: bad arguments"); return A4NT_ERR_ARG; }
+    if (!gates || !c_t || !dc_io || !dgates || (n_slabs > 0 && !dh_slabs)) { a4nt_set_error("a4nt_lstm_cell_bwd: bad arguments"); return A4NT_ERR_ARG; }
     const long long total = (long long)B * H;
     const int grid = (int)min((long long)1024, (total + 255) / 256);
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, H, gates, c_t, c_prev, dh_a,
-                       dh_b, dc_io, dgates);
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, H, gates, c_t, c_prev,
+                       dh_slabs, n_slabs, slab_stride, dh_b, ldb, dc_io, dgates);
     return a4nt_check_launch("lstm_cell_bwd");
 }
 

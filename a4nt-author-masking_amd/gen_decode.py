@@ -245,30 +245,29 @@ class _GenDecode(Function):
         coef = float(cfg['scale']) / float(cfg['tau'])
         dc = torch.zeros((B, H), device=dev)
         dG = torch.empty((n, B, 4 * H), device=dev)
-        demb_all = torch.empty((n, B, E), device=dev)
-        dh_rec, demb_next = None, None
-        ks_v = ops._auto_ksplit(B, H, V)
-        ks_r = ops._auto_ksplit(B, H + E, 4 * H)
+        # rec[t] = dgates_t * [W_hh | W_ie]: columns [0,H) = dh flowing into step t-1, [H,H+E) = d(emb input of step t)
+        rec = torch.empty((n, B, H + E), device=dev)
+        ks_v = max(1, ops._auto_ksplit(B, H, V))
+        ks_r = max(1, ops._auto_ksplit(B, H + E, 4 * H))
+        dh_slabs = torch.empty((ks_v, B, H), device=dev)
+        rec_slabs = torch.empty((ks_r, B, H + E), device=dev) if ks_r > 1 else None
         for t in range(n - 1, -1, -1):
-            if demb_next is not None:
-                gemm(demb_next, emb_W, transB=True, out=S[t], beta=1)
+            if t < n - 1:
+                gemm(rec[t + 1][:, H:], emb_W, transB=True, out=S[t], beta=1)      # += d(emb_{t+1}) * E^T
             ops.gumbel_bwd_rows(S[t], ybuf[t], stats[t], coef)                      # S[t] := dlogits_t
-            if ks_v > 1:
-                dh = slab_reduce(gemm(S[t], W_out, transB=True, ksplit=ks_v), add=dh_rec)
-            else:
-                dh = gemm(S[t], W_out, transB=True)
-                if dh_rec is not None:
-                    dh = dh + dh_rec
+            gemm(S[t], W_out, transB=True, out=dh_slabs if ks_v > 1 else dh_slabs[0], ksplit=ks_v)
             _lib.check(lib.a4nt_lstm_cell_bwd(B, H, ops._p(gates[t]), ops._p(cs[t]), ops._p(cs[t - 1] if t > 0 else None),
-                                              ops._p(dh), None, ops._p(dc), ops._p(dG[t]), s), 'a4nt_lstm_cell_bwd')
+                                              ops._p(dh_slabs), ks_v, B * H,
+                                              ops._p(rec[t + 1]) if t < n - 1 else None, H + E,
+                                              ops._p(dc), ops._p(dG[t]), s), 'a4nt_lstm_cell_bwd')
             if ks_r > 1:
-                slabs = gemm(dG[t], Wcat, ksplit=ks_r)
-                dh_rec = slab_reduce(slabs, 0, H)
-                demb_next = slab_reduce(slabs, H, E)
+                gemm(dG[t], Wcat, out=rec_slabs, ksplit=ks_r)
+                lib_rc = lib.a4nt_slab_reduce(ks_r, B * (H + E), B, H + E, ops._p(rec_slabs), H + E, 0, None, 0,
+                                              ops._p(rec[t]), H + E, s)
+                _lib.check(lib_rc, 'a4nt_slab_reduce')
             else:
-                both = gemm(dG[t], Wcat)
-                dh_rec, demb_next = both[:, :H].contiguous(), both[:, H:].contiguous()
-            demb_all[t].copy_(demb_next)
+                gemm(dG[t], Wcat, out=rec[t])
+        demb_all = rec[:, :, H:].contiguous()
         dG2 = dG.view(n * B, 4 * H)
         d_W_out = gemm_auto(hs_all[1:n + 1].reshape(n * B, H), S2, transA=True)
         d_b_out = colsum(S2)

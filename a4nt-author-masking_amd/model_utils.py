@@ -110,6 +110,6 @@ def get_classifier(params):
 
 
 def check_hidden(h, what):
-    if h < 64 or h > 512 or h % 64:
-        raise ops.A4NTError('%s = %d: the gfx950 persistent LSTM kernels support hidden sizes that are multiples of '
-                            '64 in [64, 512]' % (what, h))
+    if h not in (64, 128, 256, 512):
+        raise ops.A4NTError('%s = %d: the gfx950 persistent LSTM kernels are instantiated for hidden sizes '
+                            '64, 128, 256 and 512' % (what, h))

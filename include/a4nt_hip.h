@@ -41,6 +41,8 @@ int a4nt_sgemm(int transA, int transB, int M, int N, int K, const float* A, int 
 /* Geometry of the persistent LSTM sweeps for a batch of B rows and hidden size H
  * (H multiple of 64, 64..512): rows per group = 16*mt, groups*(H/16) workgroups <= 256. */
 int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out);
+/* 256 (default: one workgroup per CU) or 512 (two per CU; needs the GPU to itself). */
+int a4nt_lstm_set_max_workgroups(int n);
 long long a4nt_lstm_xch_floats(int B, int H, int backward);   /* exchange-buffer size (floats) */
 int a4nt_lstm_sync_words(int B, int H);                       /* sync-block size (uint32 words) */
 
@@ -82,9 +84,11 @@ int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const float* pta
                        const float* val, const float* whh, const float* c_prev, float* h_out, float* gates_out,
                        float* c_out, float* xch, void* stream);
 
-/* Element-wise cell backward of one decoder step (reverse loop of the generator). */
-int a4nt_lstm_cell_bwd(int B, int H, const float* gates, const float* c_t, const float* c_prev, const float* dh_a,
-                       const float* dh_b, float* dc_io, float* dgates, void* stream);
+/* Element-wise cell backward of one decoder step (reverse loop of the generator):
+ * dh = sum of n_slabs split-K partials [B][H] (slab_stride floats apart) + dh_b [B][ldb] (may be NULL). */
+int a4nt_lstm_cell_bwd(int B, int H, const float* gates, const float* c_t, const float* c_prev, const float* dh_slabs,
+                       int n_slabs, long long slab_stride, const float* dh_b, int ldb, float* dc_io, float* dgates,
+                       void* stream);
 
 /* Gumbel-softmax sampling row kernel: scale, log_softmax, Gumbel noise (injected uniforms U or
  * Philox(seed, step, row, v)), /tau, softmax statistics, argmax, straight-through one-hot value,

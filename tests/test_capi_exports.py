@@ -33,7 +33,13 @@ def test_argument_errors_without_gpu():
     assert lib.a4nt_lstm_geometry(128, 512, ctypes.byref(mt), ctypes.byref(g)) == 0
     assert (mt.value, g.value) == (1, 8)
     assert lib.a4nt_lstm_geometry(256, 512, ctypes.byref(mt), ctypes.byref(g)) == 0
+    assert (mt.value, g.value) == (1, 16)          # two workgroups per CU
+    assert lib.a4nt_lstm_set_max_workgroups(256) == 0
+    assert lib.a4nt_lstm_geometry(256, 512, ctypes.byref(mt), ctypes.byref(g)) == 0
     assert (mt.value, g.value) == (2, 8)
+    assert lib.a4nt_lstm_set_max_workgroups(512) == 0
+    assert lib.a4nt_lstm_geometry(512, 512, ctypes.byref(mt), ctypes.byref(g)) == 0
+    assert (mt.value, g.value) == (4, 8)
     assert lib.a4nt_lstm_geometry(5, 64, ctypes.byref(mt), ctypes.byref(g)) == 0
     assert (mt.value, g.value) == (1, 1)
     assert lib.a4nt_lstm_geometry(8, 100, ctypes.byref(mt), ctypes.byref(g)) == 1      # H not a multiple of 64

@@ -17,6 +17,9 @@ SHAPES = [  # name, M, N, K, tA, tB, ksplit
     ('dWih dG^T*x', 2048, 512, 12800, 1, 0, 4),
     ('dx dG*Wih', 12800, 512, 2048, 0, 0, 1),
     ('dec logits', 128, 10001, 512, 0, 0, 1),
+    ('dec logits ks2', 128, 10001, 512, 0, 0, 2),
+    ('dec logits ks4', 128, 10001, 512, 0, 0, 4),
+    ('dec logits ks8', 128, 10001, 512, 0, 0, 8),
     ('dec ds', 128, 10001, 512, 0, 1, 1),
     ('dec dh splitk', 128, 512, 10001, 0, 1, 16),
     ('dec rec splitk', 128, 1024, 2048, 0, 0, 8),

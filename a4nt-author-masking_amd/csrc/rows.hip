@@ -172,25 +172,26 @@ extern "C" int a4nt_gumbel_fwd(int B, int V, const float* logits, int ldl, const
     return a4nt_check_launch("gumbel_fwd");
 }
 
-// ds (in) -> dlogits (out, in place).  p = exp(y - stats[0]) / stats[1].
+// ds (in) -> dlogits (out, in place).  p = exp((y - stats[0]) * inv_tau) / stats[1]
+// (inv_tau = 1 when y already holds the tempered log-probs; 1/tau when it holds z = scale*x + g).
 __global__ __launch_bounds__(1024) void gumbel_bwd_kernel(int V, float* ds, int ldd, const float* y, int ldy,
-                                                         const float* stats, float coef) {
+                                                         const float* stats, float coef, float inv_tau) {
     __shared__ float red[ROWS_MAXW];
     const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     float* d = ds + (long long)b * ldd;
     const float* yy = y + (long long)b * ldy;
     const float m2 = stats[2 * b], inv = 1.0f / stats[2 * b + 1];
     float dot = 0.f;
-    for (int v = tid; v < V; v += NT) dot += (expf(yy[v] - m2) * inv) * d[v];
+    for (int v = tid; v < V; v += NT) dot += (expf((yy[v] - m2) * inv_tau) * inv) * d[v];
     dot = block_sum(dot, red);
-    for (int v = tid; v < V; v += NT) d[v] = coef * (expf(yy[v] - m2) * inv) * (d[v] - dot);
+    for (int v = tid; v < V; v += NT) d[v] = coef * (expf((yy[v] - m2) * inv_tau) * inv) * (d[v] - dot);
 }
 
 extern "C" int a4nt_gumbel_bwd(int B, int V, float* ds, int ldd, const float* y, int ldy, const float* stats,
-                               float coef, void* stream) {
+                               float coef, float inv_tau, void* stream) {
     if (B <= 0) return A4NT_OK;
     if (V <= 0 || !ds || !y || !stats) { a4nt_set_error("a4nt_gumbel_bwd: bad arguments"); return A4NT_ERR_ARG; }
-    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(B), dim3(V >= 4096 ? 1024 : 256), 0, (hipStream_t)stream, V, ds, ldd, y, ldy, stats, coef);
+    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(B), dim3(V >= 4096 ? 1024 : 256), 0, (hipStream_t)stream, V, ds, ldd, y, ldy, stats, coef, inv_tau);
     return a4nt_check_launch("gumbel_bwd");
 }
 

@@ -163,15 +163,15 @@ class _GenDecode(Function):
         hs_all = torch.zeros((n_max + 1, B, H), device=dev)
         gates = torch.empty((n_max, B, 4 * H), device=dev)
         cs = torch.empty((n_max, B, H), device=dev)
-        n_y = n_max if need_grad else 1
-        ybuf = None if greedy else torch.empty((n_y, B, V), device=dev)
+        # z = scale*logits + gumbel, saved per step for the backward pass only
+        ybuf = torch.empty((n_max, B, V), device=dev) if need_grad else None
         stats = torch.empty((n_max, B, 2), device=dev)
         tok = torch.zeros((n_max, B), dtype=torch.int64, device=dev)
         val_in = torch.ones((n_max, B), device=dev)
         val_out = torch.zeros((n_max, B), device=dev)
         gen_lens = torch.zeros(B, dtype=torch.int32, device=dev)
         done = torch.zeros(B, dtype=torch.uint8, device=dev)
-        logits = ops.padded_rows(B, V, dev)
+        part = torch.empty(int(lib.a4nt_proj_gumbel_part_floats(B, V)), device=dev)
         ones = torch.ones(B, device=dev)
         tok0 = tok0.contiguous()
         s = ops._s()
@@ -183,14 +183,13 @@ class _GenDecode(Function):
             _lib.check(lib.a4nt_lstm_dec_step(t, B, H, ops._p(cg), ops._p(ptab), ops._p(tk), ops._p(vl), ops._p(w_hh_c),
                                               ops._p(cp), ops._p(hs_all[t + 1]), ops._p(gates[t]), ops._p(cs[t]),
                                               ops._p(xch), s), 'a4nt_lstm_dec_step')
-            gemm(hs_all[t + 1], W_out, bias=b_out, out=logits)
             U = None
             if noise is not None and not greedy and t < len(noise):
                 U = noise[t].contiguous()      # injected uniforms (parity tests); Philox beyond the list
                 assert tuple(U.shape) == (B, V)
-            ops.gumbel_rows(logits, U, cfg.get('seed', 0), cfg.get('step0', 0) + t, cfg['scale'], cfg['tau'],
-                            cfg['hard'], greedy, None if greedy else ybuf[t if need_grad else 0], stats[t], tok[t],
-                            val_in[t], val_out[t], gen_lens, done, cfg['end_c'])
+            ops.proj_gumbel(hs_all[t + 1], W_out, b_out, U, cfg.get('seed', 0), cfg.get('step0', 0) + t, cfg['scale'],
+                            cfg['tau'], cfg['hard'], greedy, ybuf[t] if need_grad else None, part,
+                            stats[t], tok[t], val_in[t], val_out[t], gen_lens, done, cfg['end_c'])
             ran = t + 1
             if cfg['end_c'] >= 0 and (ran % CHECK_EVERY == 0) and ran < n_max and bool(done.all()):
                 break
@@ -254,7 +253,7 @@ class _GenDecode(Function):
         for t in range(n - 1, -1, -1):
             if t < n - 1:
                 gemm(rec[t + 1][:, H:], emb_W, transB=True, out=S[t], beta=1)      # += d(emb_{t+1}) * E^T
-            ops.gumbel_bwd_rows(S[t], ybuf[t], stats[t], coef)                      # S[t] := dlogits_t
+            ops.gumbel_bwd_rows(S[t], ybuf[t], stats[t], coef, 1.0 / float(cfg['tau']))   # S[t] := dlogits_t
             gemm(S[t], W_out, transB=True, out=dh_slabs if ks_v > 1 else dh_slabs[0], ksplit=ks_v)
             _lib.check(lib.a4nt_lstm_cell_bwd(B, H, ops._p(gates[t]), ops._p(cs[t]), ops._p(cs[t - 1] if t > 0 else None),
                                               ops._p(dh_slabs), ks_v, B * H,

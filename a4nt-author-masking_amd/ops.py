@@ -401,10 +401,25 @@ def gumbel_rows(logits, U, seed, step, scale, tau, hard, greedy, y, stats, tok, 
                               V if dense is not None else 0, _s()), 'a4nt_gumbel_fwd')
 
 
-def gumbel_bwd_rows(ds, y, stats, coef):
+def gumbel_bwd_rows(ds, y, stats, coef, inv_tau=1.0):
     lib = _lib.load()
     B, V = ds.shape
-    check(lib.a4nt_gumbel_bwd(B, V, _p(ds), _ld(ds), _p(y), V, _p(stats), float(coef), _s()), 'a4nt_gumbel_bwd')
+    check(lib.a4nt_gumbel_bwd(B, V, _p(ds), _ld(ds), _p(y), _ld(y), _p(stats), float(coef), float(inv_tau), _s()),
+          'a4nt_gumbel_bwd')
+
+
+def proj_gumbel(h, W, bias, U, seed, step, scale, tau, hard, greedy, z, part, stats, tok, val_in, val_out, gen_lens,
+                done, end_c):
+    """Fused decoder-step projection + Gumbel-softmax sampling (a4nt_proj_gumbel_fwd)."""
+    lib = _lib.load()
+    M, K = h.shape
+    N = W.shape[1]
+    with _Timed('proj_gumbel', 2.0 * M * N * K):
+        check(lib.a4nt_proj_gumbel_fwd(M, N, K, _p(h), _ld(h), _p(W), _ld(W), _p(bias), float(scale), float(tau),
+                                       int(hard), int(greedy), _p(U), _ld(U) if U is not None else 0, int(seed),
+                                       int(step), _p(z), _ld(z) if z is not None else 0, _p(part), _p(stats), _p(tok),
+                                       _p(val_in), _p(val_out), _p(gen_lens), _p(done), int(end_c), _s()),
+              'a4nt_proj_gumbel_fwd')
 
 
 class _GumbelDense(Function):

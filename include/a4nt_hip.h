@@ -102,7 +102,21 @@ int a4nt_gumbel_fwd(int B, int V, const float* logits, int ldl, const float* U, 
 /* In place: ds -> dlogits = coef * p * (ds - <p,ds>), p = softmax(y) from the saved y / stats.
  * Replaces: autograd backward of gumbel_softmax_sample (char_translator.py:17-28). */
 int a4nt_gumbel_bwd(int B, int V, float* ds, int ldd, const float* y, int ldy, const float* stats, float coef,
-                    void* stream);
+                    float inv_tau, void* stream);
+
+/* Fused output projection + Gumbel-softmax sampling of one free-running decoder step:
+ * z = scale*(h W + b) + gumbel(u) (greedy: z = h W + b), per-row arg max / softmax(z/tau) statistics,
+ * straight-through value, done / gen_lens bookkeeping.  All M <= rows x a 16*NT-column vocabulary strip
+ * per workgroup (v_mfma_f32_16x16x4_f32), strips merged by a finalize kernel.  z [M][ldz] is saved for
+ * a4nt_gumbel_bwd(inv_tau = 1/tau) (may be NULL); part is scratch of a4nt_proj_gumbel_part_floats().
+ * Replaces: dec_out = p_rnn.mm(W)+b; gumbel_softmax_sample(dec_out*scale, tau); argmax; done/len
+ * updates (char_translator.py:377-392) -- softmax((log_softmax(x)+g)/tau) == softmax((x+g)/tau). */
+long long a4nt_proj_gumbel_part_floats(int M, int N);
+int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh, const float* W, int ldw, const float* bias,
+                         float scale, float tau, int hard, int greedy, const float* U, int ldu,
+                         unsigned long long seed, unsigned step, float* z, int ldz, float* part, float* stats,
+                         long long* tok, float* val_in, float* val_out, int* gen_lens, unsigned char* done,
+                         long long end_c, void* stream);
 
 /* Fused log-softmax + NLL over N rows; leaves (softmax - onehot)*gscale in place of the logits when
  * write_grad.  target < 0 ignores the row.

@@ -207,3 +207,65 @@ def test_conv1d_time_major(ops, K):
     assert_close(xg.grad, xc.grad, TOLG, 'conv dx')
     assert_close(wg.grad, conv.weight.grad, TOLG, 'conv dW')
     assert_close(bg.grad, conv.bias.grad, TOLG, 'conv db')
+
+
+@pytest.mark.parametrize('M,N,K,greedy', [(128, 10001, 512, 0), (5, 51, 64, 0), (37, 301, 100, 0), (128, 10001, 512, 1),
+                                          (130, 20000, 64, 0)])
+def test_proj_gumbel_fused(ops, M, N, K, greedy):
+    """Fused projection + Gumbel sampling == (h W + b) -> reference sampler (char_translator.py:377-392)."""
+    import a4nt_amd
+    lib = a4nt_amd.load_library()
+    h, W, b = _rand(M, K, seed=61), _rand(K, N, seed=62, scale=0.2), _rand(N, seed=63)
+    U = torch.rand(M, N, generator=torch.Generator().manual_seed(64))
+    scale, tau = 3.0, 0.5
+    x = (h.double() @ W.double() + b.double())
+    if greedy:
+        zr = x
+    else:
+        g = -torch.log(-torch.log(U.double() + 1e-20) + 1e-20)
+        zr = scale * x + g
+    tok_r = zr.argmax(1)
+    s_r = torch.exp((zr - zr.max(1, keepdim=True)[0]) / tau).sum(1)
+    dev = 'cuda'
+    z = torch.zeros(M, N, device=dev)
+    part = torch.empty(int(lib.a4nt_proj_gumbel_part_floats(M, N)), device=dev)
+    stats = torch.zeros(M, 2, device=dev)
+    tok = torch.zeros(M, dtype=torch.int64, device=dev)
+    val_in, val_out = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+    lens = torch.zeros(M, dtype=torch.int32, device=dev)
+    done = torch.zeros(M, dtype=torch.uint8, device=dev)
+    done[0] = 1
+    end_c = int(tok_r[1])
+    ops.proj_gumbel(h.cuda(), W.cuda(), b.cuda(), None if greedy else U.cuda(), 0, 0, scale, tau, 1, greedy, z, part,
+                    stats, tok, val_in, val_out, lens, done, end_c)
+    assert torch.equal(tok.cpu(), tok_r), 'tokens differ'
+    assert_close(z, zr.float(), 2e-6, 'z')
+    assert_close(stats[:, 0], zr.max(1)[0].float(), 2e-6, 'max z')
+    if not greedy:
+        # exp((z - max)/tau) amplifies the fp32 rounding of z (|z| ~ 40, 1/tau = 2): conditioning, not the kernel
+        assert_close(stats[:, 1], s_r.float(), 2e-4, 'sum exp')
+        hot = ((1.0 - 1.0 / s_r.float()) + 1.0 / s_r.float())
+        assert_close(val_in, hot, 1e-6, 'val_in')
+        assert float(val_out[0]) == 0.0 and torch.equal(val_out[1:].cpu(), val_in[1:].cpu())
+    assert int(lens[0]) == 0 and bool((lens[1:] == 1).all())
+    exp_done = (tok_r == end_c)
+    exp_done[0] = True
+    assert torch.equal(done.cpu().bool(), exp_done)
+
+
+def test_proj_gumbel_philox(ops):
+    """Philox path: flat logits -> uniform token frequencies; different steps give different draws."""
+    import a4nt_amd
+    lib = a4nt_amd.load_library()
+    M, N, K = 128, 96, 64
+    h, W = torch.zeros(M, K).cuda(), torch.zeros(K, N).cuda()
+    part = torch.empty(int(lib.a4nt_proj_gumbel_part_floats(M, N))).cuda()
+    counts, toks = torch.zeros(N), []
+    for step in range(60):
+        tok = torch.zeros(M, dtype=torch.int64).cuda()
+        ops.proj_gumbel(h, W, None, None, 77, step, 3.0, 0.5, 1, 0, None, part, None, tok, None, None, None, None, -1)
+        toks.append(tok.cpu())
+        counts += torch.bincount(tok.cpu(), minlength=N).float()
+    assert not torch.equal(toks[0], toks[1])
+    expected = M * 60 / N
+    assert counts.min() > 0.55 * expected and counts.max() < 1.45 * expected

@@ -22,16 +22,14 @@ from .gen_decode import SoftSamples, sample_embed, gen_decode
 from .model_utils import (build_rec, rec_layer_params, fill_forget_bias, lens_to_device, run_stack, packed_mean,
                           check_hidden)
 
-_UNSUPPORTED = ['split_generators', 'learn_gumbel', 'no_encoder', 'apply_noise']
-
-
 class CharTranslator(nn.Module):
     def __init__(self, params, encoder_only=False):
         super().__init__()
-        for k in _UNSUPPORTED:
-            if params.get(k, 0):
-                raise NotImplementedError('a4nt_amd.CharTranslator: option %r is outside the hot-path scope' % k)
         self.encoder_only = encoder_only
+        self.no_encoder = params.get('no_encoder', 0)
+        self.enc_noise = params.get('apply_noise', 0)
+        self.learn_gumbel = params.get('learn_gumbel', False)
+        self.split_gen = params.get('split_generators', 0)
         self.encoder_mean_vec = params.get('encoder_mean_vec', 0)
         self.vocab_size = params.get('vocabulary_size', -1) + 1
         self.enc_num_rec_layers = params.get('enc_hidden_depth', -1)
@@ -45,23 +43,36 @@ class CharTranslator(nn.Module):
         self.softmax_scale = params.get('softmax_scale', 2.0)
         self.max_pool_rnn = params.get('maxpoolrnn', 0)
         self.temp = None
-        check_hidden(self.enc_hidden_size, 'enc_hidden_size')
+        if not self.no_encoder:
+            check_hidden(self.enc_hidden_size, 'enc_hidden_size')
 
         # construction order follows the reference so that a torch seed gives the same weights
+        if self.learn_gumbel:
+            self.gumbel_W = nn.Parameter(torch.zeros(self.dec_hidden_size, 1))
+            self.gumbel_b = nn.Parameter(torch.zeros(1))
         if self.pad_auth_vec:
             self.auth_emb = nn.Embedding(params.get('num_output_layers', 2), self.pad_auth_vec)
         self.char_emb = nn.Embedding(self.vocab_size, self.emb_size, padding_idx=0)
         self.p_emb = params.get('drop_prob_emb', 0.25)
-        self.enc_rec_layers = build_rec(self.emb_size, self.enc_hidden_size, self.enc_num_rec_layers, self.en_residual)
+        if not self.no_encoder:
+            self.enc_rec_layers = build_rec(self.emb_size, self.enc_hidden_size, self.enc_num_rec_layers,
+                                            self.en_residual)
         self.p_enc = params.get('drop_prob_encoder', 0.25)
         if not encoder_only:
             check_hidden(self.dec_hidden_size, 'dec_hidden_size')
-            self.ctx_size = self.enc_hidden_size * (1 + self.max_pool_rnn) + self.pad_auth_vec
+            enc_out = self.enc_hidden_size * (1 + self.max_pool_rnn) if not self.no_encoder else 0
+            self.ctx_size = enc_out + self.pad_auth_vec
             self.dec_rec_layers = build_rec(self.ctx_size + self.emb_size, self.dec_hidden_size,
                                             self.dec_num_rec_layers, self.en_residual)
             self.decoder_W = nn.Parameter(torch.zeros(self.dec_hidden_size, self.vocab_size))
             self.decoder_b = nn.Parameter(torch.zeros(self.vocab_size))
             self.p_dec = params.get('drop_prob_decoder', 0.25)
+            if self.split_gen:
+                # second decoder + output layer for batches of author 1 (char_translator.py:99-108)
+                self.dec_rec_layers_2 = build_rec(self.ctx_size + self.emb_size, self.dec_hidden_size,
+                                                  self.dec_num_rec_layers, self.en_residual)
+                self.decoder_W_2 = nn.Parameter(torch.zeros(self.dec_hidden_size, self.vocab_size))
+                self.decoder_b_2 = nn.Parameter(torch.zeros(self.vocab_size))
         self.init_weights()
         self.zero_hidden_bsz = params['batch_size']
         self._noise = None
@@ -76,9 +87,25 @@ class CharTranslator(nn.Module):
             if not self.encoder_only:
                 self.decoder_W.uniform_(-0.001, 0.001)
                 self.decoder_b.zero_()
-        fill_forget_bias(self.enc_rec_layers, self.en_residual, self.enc_num_rec_layers, self.enc_hidden_size, 1.0)
+                if self.split_gen:
+                    self.decoder_W_2.uniform_(-0.001, 0.001)
+                    self.decoder_b_2.zero_()
+            if self.learn_gumbel:
+                self.gumbel_W.uniform_(-0.01, 0.01)
+        if not self.no_encoder:
+            fill_forget_bias(self.enc_rec_layers, self.en_residual, self.enc_num_rec_layers, self.enc_hidden_size, 1.0)
         if not self.encoder_only:
             fill_forget_bias(self.dec_rec_layers, self.en_residual, self.dec_num_rec_layers, self.dec_hidden_size, 1.0)
+            if self.split_gen:
+                fill_forget_bias(self.dec_rec_layers_2, self.en_residual, self.dec_num_rec_layers,
+                                 self.dec_hidden_size, 1.0)
+
+    def _decoder(self, auths):
+        """(rec layers, W, b) of the decoder in use: the second set when split_generators is on and the
+        batch's first author id is not 0 (char_translator.py:265,273-275,359-366)."""
+        if not self.split_gen or int(auths[0]) == 0:
+            return self.dec_rec_layers, self.decoder_W, self.decoder_b
+        return self.dec_rec_layers_2, self.decoder_W_2, self.decoder_b_2
 
     # ------------------------------------------------------------------------------------------
     def set_noise(self, uniforms):
@@ -97,6 +124,11 @@ class CharTranslator(nn.Module):
         w = self.char_emb.weight
         return (w.new_zeros(self.dec_num_rec_layers, bsz, self.dec_hidden_size),
                 w.new_zeros(self.dec_num_rec_layers, bsz, self.dec_hidden_size))
+
+    def _need_encoder(self, what):
+        if self.no_encoder:
+            raise ops.A4NTError('%s needs the encoder, but this translator was built with no_encoder=1 (the reference '
+                                'has no enc_rec_layers there either, char_translator.py:73,335)' % what)
 
     def _drop(self, x, p):
         return F.dropout(x, p, True) if (self.training and p > 0.0) else x
@@ -123,41 +155,53 @@ class CharTranslator(nn.Module):
         dev = self._dev()
         soft = adv_inp or isinstance(inp, SoftSamples)
         T_in, B = inp.shape[0], inp.shape[1]
-        emb = self._embed_input(inp, soft, drop=True)
-        enc_out, enc_hidden = self._encode(emb, lengths_inp, h_prev)
-        if self.max_pool_rnn:
-            # reference: plain mean over the padded time axis of the UNPACKED output, whose length is
-            # max(lengths_inp) (char_translator.py:223-228)
-            t_eff = max(int(l) for l in lengths_inp)
-            ctxt = torch.cat([enc_out[:t_eff].mean(dim=0), enc_hidden[0][-1]], dim=-1)
-        else:
-            ctxt = enc_hidden[0][-1]
-        if sort_enc is not None:
-            ctxt = ctxt.index_select(0, sort_enc.to(dev))
-        if self.pad_auth_vec:
-            ctxt = torch.cat([ctxt, self.auth_emb(auths.to(dev))], dim=-1)
-        ctxt = self._drop(ctxt, self.p_enc)
+        enc_hidden, ctxt = None, None
+        if not self.no_encoder:
+            emb = self._embed_input(inp, soft, drop=True)
+            enc_out, enc_hidden = self._encode(emb, lengths_inp, h_prev)
+            if self.max_pool_rnn:
+                # reference: plain mean over the padded time axis of the UNPACKED output, whose length is
+                # max(lengths_inp) (char_translator.py:223-228)
+                t_eff = max(int(l) for l in lengths_inp)
+                ctxt = torch.cat([enc_out[:t_eff].mean(dim=0), enc_hidden[0][-1]], dim=-1)
+            else:
+                ctxt = enc_hidden[0][-1]
+            if sort_enc is not None:
+                ctxt = ctxt.index_select(0, sort_enc.to(dev))
+            if self.pad_auth_vec:
+                ctxt = torch.cat([ctxt, self.auth_emb(auths.to(dev))], dim=-1)
+            if self.enc_noise:
+                ctxt = ctxt + torch.randn(ctxt.shape, device=dev) / 20.       # char_translator.py:240-241
+            else:
+                ctxt = self._drop(ctxt, self.p_enc)
+        elif self.ctx_size:
+            raise ops.A4NTError('no_encoder with pad_auth_vec > 0: the decoder input would be narrower than its '
+                                'weights (the reference fails the same way, char_translator.py:86,260)')
 
         targ = targ.to(dev)
         targ_emb = self._drop(ops.embedding(targ, self.char_emb.weight, 0), self.p_emb)
         n_t = targ.shape[0]
         lens_dev = lens_to_device(lengths_targ, n_t, dev)
-        # decoder input is [ctxt, emb_t]: the ctxt half of the input contraction is loop invariant
-        w_ih0 = rec_layer_params(self.dec_rec_layers, self.en_residual, 0)[0]
-        gc = ops.linear_nk(ctxt, w_ih0[:, :self.ctx_size])
-        dec_out, dec_hidden = run_stack(self.dec_rec_layers, targ_emb, lens_dev, self.dec_num_rec_layers,
-                                        self.en_residual, None, gc0=gc, w_ih0=w_ih0[:, self.ctx_size:].contiguous())
+        dec_rec, W_out, b_out = self._decoder(auths)
+        if ctxt is not None:
+            # decoder input is [ctxt, emb_t]: the ctxt half of the input contraction is loop invariant
+            w_ih0 = rec_layer_params(dec_rec, self.en_residual, 0)[0]
+            gc = ops.linear_nk(ctxt, w_ih0[:, :self.ctx_size])
+            dec_out, dec_hidden = run_stack(dec_rec, targ_emb, lens_dev, self.dec_num_rec_layers, self.en_residual,
+                                            None, gc0=gc, w_ih0=w_ih0[:, self.ctx_size:].contiguous())
+        else:
+            dec_out, dec_hidden = run_stack(dec_rec, targ_emb, lens_dev, self.dec_num_rec_layers, self.en_residual, None)
         n_eff = max(int(l) for l in lengths_targ)
         dec_out = self._drop(dec_out[:n_eff], self.p_dec)
-        return dec_out, n_eff, B, (enc_hidden, dec_hidden)
+        return dec_out, n_eff, B, (enc_hidden, dec_hidden), W_out, b_out
 
     def forward_mltrain(self, inp, lengths_inp, targ, lengths_targ, h_prev=None, compute_softmax=False, auths=None,
                         adv_inp=False, sort_enc=None, adv_targ=False):
         if adv_targ:
             raise NotImplementedError('adv_targ (language-model loss) is outside the hot-path scope')
-        dec_out, n_t, B, hidden = self._mltrain_hidden(inp, lengths_inp, targ, lengths_targ, h_prev, auths, adv_inp,
-                                                       sort_enc)
-        score = ops.linear_kn(dec_out.reshape(n_t * B, -1), self.decoder_W, self.decoder_b)
+        dec_out, n_t, B, hidden, W_out, b_out = self._mltrain_hidden(inp, lengths_inp, targ, lengths_targ, h_prev, auths,
+                                                                     adv_inp, sort_enc)
+        score = ops.linear_kn(dec_out.reshape(n_t * B, -1), W_out, b_out)
         if compute_softmax:
             score = F.log_softmax(score, dim=1)
         return score.view(n_t, B, self.vocab_size), hidden
@@ -167,18 +211,19 @@ class CharTranslator(nn.Module):
         """CrossEntropyLoss(pack(forward_mltrain(...)[0], lens), pack(targ_out, lens)) with the vocab
         projection fused into the log-softmax/NLL kernel (train_translator.py:111-113;
         train_adversarial_translator.py:176-177,661-664)."""
-        dec_out, n_t, B, _ = self._mltrain_hidden(inp, lengths_inp, targ_in, lengths_targ, h_prev, auths, adv_inp,
-                                                  sort_enc)
+        dec_out, n_t, B, _, W_out, b_out = self._mltrain_hidden(inp, lengths_inp, targ_in, lengths_targ, h_prev, auths,
+                                                                adv_inp, sort_enc)
         dev = self._dev()
         tgt = targ_out[:n_t].to(dev).clone()
         steps = torch.arange(n_t, device=dev).view(-1, 1)
         lens_t = torch.as_tensor([int(l) for l in lengths_targ], device=dev).view(1, -1)
         tgt[steps >= lens_t] = -1
         n_valid = int(sum(min(int(l), n_t) for l in lengths_targ))
-        return ops.proj_nll(dec_out.reshape(n_t * B, -1), self.decoder_W, self.decoder_b, tgt.view(-1), n_valid)
+        return ops.proj_nll(dec_out.reshape(n_t * B, -1), W_out, b_out, tgt.view(-1), n_valid)
 
     # -- encoder only (char_translator.py:288-312) ----------------------------------------------
     def forward_encode(self, x, lengths_inp, h_prev=None, adv_inp=False):
+        self._need_encoder('forward_encode')
         emb = self._embed_input(x, adv_inp, drop=False)
         enc_out, enc_hidden = self._encode(emb, lengths_inp, h_prev)
         if self.encoder_mean_vec:
@@ -188,6 +233,7 @@ class CharTranslator(nn.Module):
     # -- free running generation (char_translator.py:314-401) -----------------------------------
     def forward_advers_gen(self, x, lengths_inp, h_prev=None, n_max=100, end_c=-1, soft_samples=False, temp=0.1,
                            auths=None, adv_inp=False, n_samples=1, compact=False):
+        self._need_encoder('forward_advers_gen')
         dev = self._dev()
         soft_in = adv_inp or isinstance(x, SoftSamples)
         B = x.shape[1]
@@ -201,17 +247,18 @@ class CharTranslator(nn.Module):
             ctxt = torch.cat([ctxt, self.auth_emb(auths.to(dev))], dim=-1)
         if soft_samples:
             self.temp = temp
-        fused = (self.dec_num_rec_layers == 1 and not soft_in and n_samples == 1 and
+        dec = self._decoder(auths)
+        fused = (self.dec_num_rec_layers == 1 and not soft_in and n_samples == 1 and not self.learn_gumbel and
                  (self.gumb_type or not soft_samples))
         if not fused:
-            return self._advers_gen_generic(x, soft_in, ctxt, n_max, end_c, soft_samples, temp, n_samples, compact)
-        w_ih, w_hh, b_ih, b_hh = rec_layer_params(self.dec_rec_layers, self.en_residual, 0)
+            return self._advers_gen_generic(x, soft_in, ctxt, n_max, end_c, soft_samples, temp, n_samples, compact, dec)
+        w_ih, w_hh, b_ih, b_hh = rec_layer_params(dec[0], self.en_residual, 0)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         cfg = dict(n_max=n_max, end_c=int(end_c), tau=float(temp), scale=float(self.softmax_scale),
                    hard=bool(self.gumb_type), greedy=not soft_samples, need_grad=need_grad, noise=self._noise,
                    seed=self.noise_seed, step0=self._noise_step)
         samples, gen_lens, tok = gen_decode(ctxt, x[0].to(dev), self.char_emb.weight, w_ih, w_hh, b_ih, b_hh,
-                                            self.decoder_W, self.decoder_b, cfg)
+                                            dec[1], dec[2], cfg)
         self._noise_step += n_max
         char_out = list(tok.unbind(0))
         if not soft_samples:
@@ -220,10 +267,11 @@ class CharTranslator(nn.Module):
             return samples, gen_lens, char_out
         return list(samples.to_dense().unbind(0)), gen_lens, char_out
 
-    def _advers_gen_generic(self, x, soft_in, ctxt, n_max, end_c, soft_samples, temp, n_samples, compact):
+    def _advers_gen_generic(self, x, soft_in, ctxt, n_max, end_c, soft_samples, temp, n_samples, compact, dec):
         """Step-by-step composition of the same HIP operators (stacked / residual decoders, soft
-        (non straight-through) samples, soft encoder input, n_samples > 1): follows the reference loop
-        literally, including its per-step host check."""
+        (non straight-through) samples, soft encoder input, n_samples > 1, learnt temperature): follows
+        the reference loop literally, including its per-step host check."""
+        dec_rec, W_out, b_out = dec
         if compact:
             raise NotImplementedError('compact samples need the fused path (1-layer decoder, gumbel_hard, hard input)')
         dev = self._dev()
@@ -237,18 +285,21 @@ class CharTranslator(nn.Module):
         dec_bsz = B * n_samples
         ctxt_rep = ctxt.repeat(n_samples, 1)
         dec_inp = torch.cat([ctxt, targ_emb], dim=-1).repeat(n_samples, 1)
-        out, dec_hidden = run_stack(self.dec_rec_layers, dec_inp.view(1, dec_bsz, -1), None, self.dec_num_rec_layers,
+        out, dec_hidden = run_stack(dec_rec, dec_inp.view(1, dec_bsz, -1), None, self.dec_num_rec_layers,
                                     self.en_residual, None)
         p_rnn = out.view(dec_bsz, -1)
         char_out, samp_out = [], []
         gen_lens = torch.zeros(dec_bsz, dtype=torch.int32, device=dev)
         prev_done = torch.zeros(dec_bsz, dtype=torch.bool, device=dev)
         for _ in range(n_max):
-            dec_out = ops.linear_kn(p_rnn, self.decoder_W, self.decoder_b)
+            dec_out = ops.linear_kn(p_rnn, W_out, b_out)
             if soft_samples:
                 U = self._noise.pop(0) if self._noise is not None else None
-                samp, pred_c = ops.gumbel_dense(dec_out * self.softmax_scale, U, self.noise_seed, self._noise_step,
-                                                float(temp), bool(self.gumb_type))
+                if self.learn_gumbel:
+                    samp, pred_c = self._gumbel_learnt_tau(dec_out * self.softmax_scale, p_rnn, U)
+                else:
+                    samp, pred_c = ops.gumbel_dense(dec_out * self.softmax_scale, U, self.noise_seed, self._noise_step,
+                                                    float(temp), bool(self.gumb_type))
                 self._noise_step += 1
                 emb = ops.linear_kn(samp, self.char_emb.weight)
                 char_out.append(pred_c)
@@ -263,10 +314,24 @@ class CharTranslator(nn.Module):
             if bool(prev_done.all()):
                 break
             dec_inp = torch.cat([ctxt_rep, emb], dim=-1).view(1, dec_bsz, -1)
-            out, dec_hidden = run_stack(self.dec_rec_layers, dec_inp, None, self.dec_num_rec_layers, self.en_residual,
-                                        dec_hidden)
+            out, dec_hidden = run_stack(dec_rec, dec_inp, None, self.dec_num_rec_layers, self.en_residual, dec_hidden)
             p_rnn = out.view(dec_bsz, -1)
         return samp_out, gen_lens, char_out
+
+    def _gumbel_learnt_tau(self, x, p_rnn, U):
+        """Gumbel-softmax with one learnt temperature per row, tau = softplus(p_rnn*gumbel_W + b) + 1
+        (char_translator.py:379).  softmax((log_softmax(x)+g)/tau) = softmax(log(softmax(x+g))/tau): the
+        tau = 1 row kernel supplies softmax(x+g) (and its backward); the per-row rescale, which carries the
+        gradient to gumbel_W / gumbel_b, is elementwise torch on that row."""
+        tau = F.softplus(ops.linear_kn(p_rnn, self.gumbel_W, self.gumbel_b)) + 1.0           # [B,1]
+        self.temp = tau
+        y1, _ = ops.gumbel_dense(x, U, self.noise_seed, self._noise_step, 1.0, False)
+        ysft = F.softmax(torch.log(y1.clamp_min(1e-37)) / tau, dim=1)
+        pred_c = ysft.detach().argmax(dim=1)
+        if self.gumb_type:
+            hard = torch.zeros_like(ysft).scatter_(1, pred_c.view(-1, 1), 1.0)
+            return (hard - ysft.detach()) + ysft, pred_c
+        return ysft, pred_c
 
     def forward_gen(self, x, h_prev=None, auths=None, n_max=100, end_c=-1, soft_samples=False, temp=0.1):
         """B = 1 sampler of the reference's demo script (char_translator.py:403-469); greedy only (the

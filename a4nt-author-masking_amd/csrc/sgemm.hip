@@ -166,6 +166,12 @@ static int launch_sgemm(GemmArgs g, int ksplit, hipStream_t s) {
 }
 
 // C-ABI entry: see include/a4nt_hip.h
+// Workgroup tile edge a4nt_sgemm picks: 128x128 tiles when they still fill the chip, 64x64 otherwise.
+extern "C" int a4nt_sgemm_tile(int M, int N, int ksplit) {
+    const long long big_tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * (ksplit < 1 ? 1 : ksplit);
+    return big_tiles >= 200 ? 128 : 64;
+}
+
 extern "C" int a4nt_sgemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                           int ldb, float* C, int ldc, const float* bias, int beta, int ksplit, long long slab_stride,
                           void* stream) {
@@ -188,9 +194,7 @@ extern "C" int a4nt_sgemm(int transA, int transB, int M, int N, int K, const flo
     g.slab = slab_stride;
     g.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    // tile choice: big 128x128 tiles when they still fill the chip, 64x64 otherwise
-    const long long big_tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * ksplit;
-    const bool big = big_tiles >= 200;
+    const bool big = a4nt_sgemm_tile(M, N, ksplit) == 128;
     if (!transA && !transB) return big ? launch_sgemm<false, false, 2, 2, PFB>(g, ksplit, s) : launch_sgemm<false, false, 1, 1, PFS>(g, ksplit, s);
     if (!transA && transB) return big ? launch_sgemm<false, true, 2, 2, PFB>(g, ksplit, s) : launch_sgemm<false, true, 1, 1, PFS>(g, ksplit, s);
     return big ? launch_sgemm<true, false, 2, 2, PFB>(g, ksplit, s) : launch_sgemm<true, false, 1, 1, PFS>(g, ksplit, s);

@@ -31,7 +31,9 @@ def _f32(t, what):
     return t
 
 
-# Optional per-kernel timing for bench.py's roofline line: TIMER = {'name': <kernel family>, 'events': []}.
+# Optional per-kernel timing for bench.py's roofline line: TIMER = {'name': <kernel label>, 'events': []}.
+# Labels: 'sgemm_<nn|nt|tn>_<128|64>' (one per sgemm_kernel instantiation), 'lstm_seq_fwd',
+# 'lstm_seq_bwd', 'proj_gumbel'.
 # Events are recorded on torch's current stream, which is the stream every kernel here is launched on.
 TIMER = None
 
@@ -90,7 +92,10 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, beta=0, ksplit=1
         if not beta:
             out.zero_()
         return out
-    with _Timed('sgemm', 2.0 * M * N * K):
+    label = None
+    if TIMER is not None:
+        label = 'sgemm_%s_%d' % ('tn' if transA else ('nt' if transB else 'nn'), lib.a4nt_sgemm_tile(M, N, int(ksplit)))
+    with _Timed(label, 2.0 * M * N * K):
         check(lib.a4nt_sgemm(int(transA), int(transB), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc,
                              _p(bias), int(beta), int(ksplit), M * ldc if ksplit > 1 else 0, _s()), 'a4nt_sgemm')
     return out
@@ -114,15 +119,29 @@ def slab_reduce(slabs, c0=0, ncols=None, add=None):
 
 
 def _auto_ksplit(M, N, K):
-    """Split K when the 128x128 tiling would leave most of the 256 CUs idle (a4nt_sgemm picks the
-    128x128 kernel once tiles*ksplit >= 200, the latency-tolerant 64x64 one otherwise)."""
+    """Split-K factor for gemm_auto.
+
+    Few output tiles: split K so that the 256 CUs have work (a4nt_sgemm picks the 128x128 kernel once
+    tiles*ksplit >= 200, the latency-tolerant 64x64 one otherwise).  Many tiles: the 128x128 kernel runs
+    at ~0.48 TFLOP/s per CU (the fp32 MFMA rate at the clock the chip holds), so the launch takes
+    ceil(tiles*ks/256) rounds of one K/ks-deep tile each; a tile count just above a multiple of 256
+    (316 tiles for the [512 x 10001] weight gradient) wastes most of a round, and splitting K trades
+    that for the slab write + reduce traffic.  Pick the cheapest under that model."""
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
-    if t128 >= 160 or K < 1024:
+    if K < 1024:
         return 1
-    t64 = ((M + 63) // 64) * ((N + 63) // 64)
-    if t128 >= 32:                       # enough big tiles: aim for ~256-512 of them
-        return int(max(1, min((256 + t128 - 1) // t128, K // 512, 32)))
-    return int(max(1, min(512 // max(t64, 1), K // 256, 32)))
+    if t128 < 32:
+        t64 = ((M + 63) // 64) * ((N + 63) // 64)
+        return int(max(1, min(512 // max(t64, 1), K // 256, 32)))
+    best, best_t = 1, None
+    for ks in range(1, int(min(16, K // 512)) + 1):
+        rounds = (t128 * ks + 255) // 256
+        t = rounds * (0.06875 * ((K + ks - 1) // ks) + 4.0)                 # us
+        if ks > 1:
+            t += (2 * ks + 1) * M * N * 4 / 3.5e6 + 6.0                     # slab write + reduce pass
+        if best_t is None or t < 0.97 * best_t:
+            best, best_t = ks, t
+    return best
 
 
 def gemm_auto(A, B, transA=False, transB=False, bias=None):

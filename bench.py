@@ -61,9 +61,10 @@ def adv_step(impl, G, D, optG, optD, batches, it, batch, reducers):
     return rd, rg
 
 
-def cpu_baseline(batch_cpu=32):
+def cpu_baseline(batch_cpu=B):
     """The oracle (pure-PyTorch CPU restatement pinned to the reference by tests/golden) timed on
-    this host's cores on a bounded sample: ONE adversarial step at a reduced batch."""
+    this host's cores on a bounded sample: ONE adversarial step at the benchmark's batch (about 10-25 s
+    on the GPU box's 16-thread CPU share)."""
     import oracle
     torch.manual_seed(0)
     threads = min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1)))
@@ -86,6 +87,19 @@ def cpu_baseline(batch_cpu=32):
                       'V=%d, oracle/ on torch CPU fp32, %.1f s' % (batch_cpu, B, T, V + 1, dt)}
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and
+    WRITE_SIZE runs of this same command); None when that kernel has no entry."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        tab = json.load(f)
+    ent = tab.get('kernels', {}).get(label)
+    return ent['hbm_bytes_per_launch'] if ent else None
+
+
 def _synth(g, batch):
     inps = torch.zeros(T, batch, dtype=torch.long)
     targs = torch.zeros(T, batch, dtype=torch.long)
@@ -104,7 +118,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=B, help='sentences per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--roofline-kernel', default='lstm_seq_fwd')
+    ap.add_argument('--roofline-kernel', default='sgemm_tn_128',
+                    help='kernel timed with HIP events inside the timed region (default: the kernel with the '
+                         'largest share of the step in profiles/: sgemm_kernel<true,false,2,2,2>)')
+    ap.add_argument('--no-extra-rooflines', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -150,12 +167,30 @@ def main():
     dt = float(tmax.item())
     loss_ok = bool(torch.isfinite(rd['loss']).item() and torch.isfinite(rg['loss']).item())
 
+    def summarise(tm):
+        flops = sum(f for _, _, f in tm['events'])
+        secs = sum(e0.elapsed_time(e1) for e0, e1, _ in tm['events']) / 1000.0
+        n = max(1, len(tm['events']))
+        ach = flops / secs / 1e12 if secs > 0 else 0.0
+        return {'kernel': tm['name'], 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'launches': len(tm['events']),
+                'avg_launch_ms': secs * 1000.0 / n, 'gflop_per_launch': flops / n / 1e9}
+
+    # the other MFMA kernels of the step, one untimed extra step each (outside the timed region)
+    others = []
+    if world == 1 and not args.no_extra_rooflines:
+        for name in ('lstm_seq_fwd', 'lstm_seq_bwd', 'proj_gumbel', 'sgemm_nt_128', 'sgemm_nn_128', 'sgemm_nt_64'):
+            if name == timer['name']:
+                continue
+            ops.TIMER = {'name': name, 'events': []}
+            adv_step(impl, G, D, optG, optD, batches, args.warmup + args.steps, args.batch, (None, None))
+            torch.cuda.synchronize()
+            tm, ops.TIMER = ops.TIMER, None
+            others.append(summarise(tm))
+
     if rank == 0:
         ms = dt * 1000.0 / args.steps
-        flops = sum(f for _, _, f in timer['events'])
-        secs = sum(e0.elapsed_time(e1) for e0, e1, _ in timer['events']) / 1000.0
-        n_launch = max(1, len(timer['events']))
-        ach = flops / secs / 1e12 if secs > 0 else 0.0
+        main_rl = summarise(timer)
         line = {
             'metric': 'adversarial train sentences/sec (node)', 'value': world * args.batch / (dt / args.steps),
             'unit': 'sentences/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
@@ -164,10 +199,10 @@ def main():
                                    'char_lstm discriminator, ml reconstruction loss); translator enc/dec 1x512, '
                                    'discriminator 2x512, V=10001, E=512, T=100, batch %d/GPU, all lens=T' % args.batch,
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'losses_finite': loss_ok},
-            'roofline': {'bound': 'mfma', 'kernel': timer['name'], 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
-                         'launches': len(timer['events']), 'avg_launch_ms': secs * 1000.0 / n_launch},
+            'roofline': dict({'bound': 'mfma', 'traffic': pmc_traffic(timer['name'])}, **main_rl),
         }
+        if others:
+            line['roofline']['other_kernels'] = others
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line))

@@ -37,6 +37,9 @@ int a4nt_init(int device, int* num_cus);
  * every autograd backward of those. */
 int a4nt_sgemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                float* C, int ldc, const float* bias, int beta, int ksplit, long long slab_stride, void* stream);
+/* Workgroup tile edge (128 or 64) a4nt_sgemm uses for this shape; lets the caller label a launch for
+ * profiling.  Nothing in the reference corresponds (torch picks its BLAS kernel internally). */
+int a4nt_sgemm_tile(int M, int N, int ksplit);
 
 /* Geometry of the persistent LSTM sweeps for a batch of B rows and hidden size H
  * (H multiple of 64, 64..512): rows per group = 16*mt, groups*(H/16) workgroups <= 256. */

@@ -128,6 +128,10 @@ def scale_weights(model, factor_W=200.0):
     see well-separated logits; this is 'identical weights' for both sides, so parity is unaffected."""
     with torch.no_grad():
         model.decoder_W.mul_(factor_W)
+        if hasattr(model, 'decoder_W_2'):
+            model.decoder_W_2.mul_(factor_W)
+        if hasattr(model, 'gumbel_W'):
+            model.gumbel_W.mul_(100.0)          # so that the learnt temperature differs between rows
 
 
 # ------------------------------------------------------------------------------------------
@@ -249,6 +253,80 @@ def fx_advers_gen(ct):
                 char_outs=torch.stack(list(co), 0))
     arrs.update(sd_np(m, 'sd.'))
     save('gen_greedy', p, **arrs)
+
+
+def fx_translator_options(ct):
+    """Constructor options off the default path: split generators (second decoder for author 1), learnt
+    Gumbel temperature, soft (non straight-through) samples with n_samples = 2, soft encoder input,
+    decoder-only translator."""
+    from torch.nn.utils.rnn import pack_padded_sequence as pps
+    # teacher forced, second decoder / no encoder
+    for name, over, a in (('mltrain_split', dict(split_generators=1), 1),
+                          ('mltrain_noenc', dict(no_encoder=1, pad_auth_vec=0), 0)):
+        g = torch.Generator().manual_seed(23)
+        torch.manual_seed(12)
+        p = gen_params(**over)
+        m = ct.CharTranslator(p)
+        scale_weights(m, 100.0)
+        m.train()
+        T, B = 7, 5
+        inps, targs, lens = synth_batch(g, T, B, V0)
+        auths = torch.LongTensor([a] * B)
+        scores, _ = m.forward_mltrain(inps, lens, inps, lens, auths=auths)
+        loss = nn.functional.cross_entropy(pps(scores, lens)[0], pps(targs, lens)[0])
+        loss.backward()
+        arrs = dict(inps=inps, targs=targs, lens=np.array(lens), auths=auths, scores=scores, loss=loss)
+        arrs.update(sd_np(m, 'sd.'))
+        arrs.update(grads_np(m, 'grad.'))
+        save(name, p, **arrs)
+
+    # free running
+    cases = (('gen_soft_split', dict(split_generators=1), dict(), 1),
+             ('gen_soft_learntau', dict(learn_gumbel=True), dict(), 1),
+             ('gen_soft_nsamp2_st0', dict(gumbel_hard=False), dict(n_samples=2), 0),
+             ('gen_soft_advinp', dict(), dict(adv_inp=True), 1))
+    for name, over, kw, a in cases:
+        g = torch.Generator().manual_seed(33)
+        torch.manual_seed(13)
+        p = gen_params(**over)
+        m = ct.CharTranslator(p)
+        scale_weights(m, 300.0)
+        m.train()
+        T, B = 6, 4
+        inps, targs, lens = synth_batch(g, T, B, V0)
+        auths = torch.LongTensor([a] * B)
+        x = inps
+        if kw.get('adv_inp'):
+            x = torch.softmax(torch.randn(T, B, V0 + 1, generator=g) * 3, dim=-1)
+            for b, L in enumerate(lens):
+                x[L:, b] = 0
+            x.requires_grad_(True)
+        n_max = T + 2
+        noise = Noise(79)
+        ct.sample_gumbel = noise.sample_gumbel
+        s, gl, co = m.forward_advers_gen(x, lens, soft_samples=True, temp=0.5, n_max=n_max, end_c=-1, auths=auths, **kw)
+        end_c = int(co[2][1])
+        noise.replay = [u.clone() for u in noise.drawn]
+        m.zero_grad()
+        if kw.get('adv_inp'):
+            x.grad = None
+        s, gl, co = m.forward_advers_gen(x, lens, soft_samples=True, temp=0.5, n_max=n_max, end_c=end_c, auths=auths, **kw)
+        samp = torch.stack(list(s), 0)
+        R = torch.randn(samp.shape, generator=g)
+        loss = (samp * R).sum()
+        loss.backward()
+        arrs = dict(inps=inps, lens=np.array(lens), auths=auths, n_max=n_max, end_c=end_c, temp=0.5,
+                    samp=samp, gen_lens=gl, char_outs=torch.stack(list(co), 0), R=R, loss=loss,
+                    n_samples=kw.get('n_samples', 1))
+        if kw.get('adv_inp'):
+            arrs['soft'] = x.detach()
+            arrs['dsoft'] = x.grad
+        for i, u in enumerate(noise.drawn):
+            arrs['u%d' % i] = u
+        arrs['n_noise'] = len(noise.drawn)
+        arrs.update(sd_np(m, 'sd.'))
+        arrs.update(grads_np(m, 'grad.'))
+        save(name, p, **arrs)
 
 
 def fx_charlstm(cl):
@@ -396,6 +474,10 @@ def fx_init(ct, cl):
 
 if __name__ == '__main__':
     ct, cl, cc, mu = install_shim()
+    if sys.argv[1:] == ['options']:           # only the fixtures added after the first set
+        fx_translator_options(ct)
+        sys.exit(0)
+    fx_translator_options(ct)
     fx_gumbel(ct)
     fx_translator_mltrain(ct)
     fx_advers_gen(ct)

@@ -10,9 +10,9 @@ Follows, function by function (citations are into /root/reference):
 Differences from the reference are limited to what a Python-3 / device-agnostic restatement
 needs: no ``.cuda()`` in constructors, tensors follow the parameters' device, and every random
 draw of the Gumbel sampler goes through an injectable ``NoiseSource`` so fixtures can pin it.
-Options outside SURVEY.md section 8 (split generators, learnt temperature, bidirectional /
-compression / MLP / CNN-over-hidden classifier heads, generative LM heads) raise
-NotImplementedError instead of being silently approximated.
+Options outside SURVEY.md section 8 (bidirectional / compression / MLP / CNN-over-hidden classifier
+heads, generative LM heads, the adv_targ language-model input) raise NotImplementedError instead of
+being silently approximated.
 """
 import math
 
@@ -58,7 +58,8 @@ def sample_gumbel(shape, noise, device):
 
 
 def gumbel_softmax_sample(x, tau, hard, noise):
-    """char_translator.py:17-28.  x: [B,V] (already multiplied by softmax_scale)."""
+    """char_translator.py:17-28.  x: [B,V] (already multiplied by softmax_scale); tau: float, or a
+    [B,1] tensor when the temperature is learnt (char_translator.py:379)."""
     g = sample_gumbel(x.shape, noise, x.device)
     y = (F.log_softmax(x, dim=1) + g) / tau
     ysft = F.softmax(y, dim=1)
@@ -131,8 +132,11 @@ def _unsupported(params, keys):
 class CharTranslator(nn.Module):
     def __init__(self, params, encoder_only=False, noise=None):
         super().__init__()
-        _unsupported(params, ['split_generators', 'learn_gumbel', 'no_encoder', 'apply_noise'])
         self.encoder_only = encoder_only
+        self.no_encoder = params.get('no_encoder', 0)
+        self.enc_noise = params.get('apply_noise', 0)
+        self.learn_gumbel = params.get('learn_gumbel', False)
+        self.split_gen = params.get('split_generators', 0)
         self.encoder_mean_vec = params.get('encoder_mean_vec', 0)
         self.vocab_size = params.get('vocabulary_size', -1) + 1
         self.enc_num_rec_layers = params.get('enc_hidden_depth', -1)
@@ -148,20 +152,31 @@ class CharTranslator(nn.Module):
         self.noise = noise if noise is not None else NoiseSource()
         self.temp = None
 
+        if self.learn_gumbel:
+            self.gumbel_W = nn.Parameter(torch.zeros(self.dec_hidden_size, 1))
+            self.gumbel_b = nn.Parameter(torch.zeros(1))
         if self.pad_auth_vec:
             self.auth_emb = nn.Embedding(params.get('num_output_layers', 2), self.pad_auth_vec)
         self.char_emb = nn.Embedding(self.vocab_size, self.emb_size, padding_idx=0)
         self.emb_drop = nn.Dropout(p=params.get('drop_prob_emb', 0.25))
-        self.enc_rec_layers = _build_rec(self.emb_size, self.enc_hidden_size, self.enc_num_rec_layers,
-                                         self.en_residual)
-        self.enc_drop = nn.Dropout(p=params.get('drop_prob_encoder', 0.25))
+        if not self.no_encoder:
+            self.enc_rec_layers = _build_rec(self.emb_size, self.enc_hidden_size, self.enc_num_rec_layers,
+                                             self.en_residual)
+            self.enc_drop = nn.Dropout(p=params.get('drop_prob_encoder', 0.25))
         if not encoder_only:
-            in_sz = self.enc_hidden_size * (1 + self.max_pool_rnn) + self.emb_size + self.pad_auth_vec
+            enc_out = self.enc_hidden_size * (1 + self.max_pool_rnn) if not self.no_encoder else 0
+            in_sz = enc_out + self.emb_size + self.pad_auth_vec
             self.dec_rec_layers = _build_rec(in_sz, self.dec_hidden_size, self.dec_num_rec_layers,
                                              self.en_residual)
             self.decoder_W = nn.Parameter(torch.zeros(self.dec_hidden_size, self.vocab_size))
             self.decoder_b = nn.Parameter(torch.zeros(self.vocab_size))
             self.dec_drop = nn.Dropout(p=params.get('drop_prob_decoder', 0.25))
+            if self.split_gen:
+                # second decoder + output layer, used for batches of author 1 (char_translator.py:99-108)
+                self.dec_rec_layers_2 = _build_rec(in_sz, self.dec_hidden_size, self.dec_num_rec_layers,
+                                                   self.en_residual)
+                self.decoder_W_2 = nn.Parameter(torch.zeros(self.dec_hidden_size, self.vocab_size))
+                self.decoder_b_2 = nn.Parameter(torch.zeros(self.vocab_size))
         self.init_weights()
         self.zero_hidden_bsz = params['batch_size']
 
@@ -170,8 +185,16 @@ class CharTranslator(nn.Module):
             with torch.no_grad():
                 self.decoder_W.uniform_(-0.001, 0.001)
                 self.decoder_b.zero_()
-        for rec, depth, hsz in ((self.enc_rec_layers, self.enc_num_rec_layers, self.enc_hidden_size),
+                if self.split_gen:
+                    self.decoder_W_2.uniform_(-0.001, 0.001)
+                    self.decoder_b_2.zero_()
+        if self.learn_gumbel:
+            with torch.no_grad():
+                self.gumbel_W.uniform_(-0.01, 0.01)
+        for rec, depth, hsz in ((getattr(self, 'enc_rec_layers', None), self.enc_num_rec_layers, self.enc_hidden_size),
                                 (getattr(self, 'dec_rec_layers', None), self.dec_num_rec_layers,
+                                 self.dec_hidden_size),
+                                (getattr(self, 'dec_rec_layers_2', None), self.dec_num_rec_layers,
                                  self.dec_hidden_size)):
             if rec is None:
                 continue
@@ -207,6 +230,13 @@ class CharTranslator(nn.Module):
         packed = pack_padded_sequence(emb, lengths)
         return _run_rec(self.enc_rec_layers, packed, h_prev, self.en_residual, self.enc_num_rec_layers)
 
+    def _decoder(self, auths):
+        """(rec layers, W, b) of the decoder in use: the second one when split_generators is set and the
+        batch's first author id is not 0 (char_translator.py:265,273-275,359-366)."""
+        if not self.split_gen or int(auths[0]) == 0:
+            return self.dec_rec_layers, self.decoder_W, self.decoder_b
+        return self.dec_rec_layers_2, self.decoder_W_2, self.decoder_b_2
+
     # -- teacher forced (char_translator.py:200-286) -------------------------------------------
     def forward_mltrain(self, inp, lengths_inp, targ, lengths_targ, h_prev=None, compute_softmax=False,
                         auths=None, adv_inp=False, sort_enc=None, adv_targ=False):
@@ -214,34 +244,43 @@ class CharTranslator(nn.Module):
             raise NotImplementedError('oracle: adv_targ (language-model loss) is out of scope')
         dev = self._dev()
         b_sz = inp.shape[1]
-        if not adv_inp:
-            emb = self.emb_drop(self.char_emb(inp.to(dev)))
-        else:
-            emb = self._soft_embed(inp)
-        enc_out, enc_hidden = self._encode(emb, lengths_inp, h_prev)
-        if self.max_pool_rnn:
-            enc_unp, _ = pad_packed_sequence(enc_out)
-            # reference: plain mean over the padded time axis (char_translator.py:227)
-            ctxt = torch.cat([enc_unp.mean(dim=0), enc_hidden[0][-1]], dim=-1)
-        else:
-            ctxt = enc_hidden[0][-1]
-        if sort_enc is not None:
-            ctxt = ctxt.index_select(0, sort_enc.to(dev))
-        if self.pad_auth_vec:
-            ctxt = torch.cat([ctxt, self.auth_emb(auths.to(dev))], dim=-1)
-        ctxt = self.enc_drop(ctxt)
+        enc_hidden = None
+        if not self.no_encoder:
+            if not adv_inp:
+                emb = self.emb_drop(self.char_emb(inp.to(dev)))
+            else:
+                emb = self._soft_embed(inp)
+            enc_out, enc_hidden = self._encode(emb, lengths_inp, h_prev)
+            if self.max_pool_rnn:
+                enc_unp, _ = pad_packed_sequence(enc_out)
+                # reference: plain mean over the padded time axis (char_translator.py:227)
+                ctxt = torch.cat([enc_unp.mean(dim=0), enc_hidden[0][-1]], dim=-1)
+            else:
+                ctxt = enc_hidden[0][-1]
+            if sort_enc is not None:
+                ctxt = ctxt.index_select(0, sort_enc.to(dev))
+            if self.pad_auth_vec:
+                ctxt = torch.cat([ctxt, self.auth_emb(auths.to(dev))], dim=-1)
+            if self.enc_noise:
+                # char_translator.py:240-241: N(0,1)/20 noise instead of dropout (global RNG: not pinned)
+                ctxt = ctxt + torch.randn(ctxt.shape, device=dev) / 20.
+            else:
+                ctxt = self.enc_drop(ctxt)
 
         targ = targ.to(dev)
         targ_emb = self.emb_drop(self.char_emb(targ))
         n_t = targ.shape[0]
-        dec_inp = torch.cat([ctxt.unsqueeze(0).expand(n_t, b_sz, ctxt.shape[1]), targ_emb], dim=-1)
+        if not self.no_encoder:
+            dec_inp = torch.cat([ctxt.unsqueeze(0).expand(n_t, b_sz, ctxt.shape[1]), targ_emb], dim=-1)
+        else:
+            dec_inp = targ_emb
         packed = pack_padded_sequence(dec_inp, lengths_targ)
-        dec_out, dec_hidden = _run_rec(self.dec_rec_layers, packed, None, self.en_residual,
-                                       self.dec_num_rec_layers)
+        dec_rec, dec_W, dec_b = self._decoder(auths)
+        dec_out, dec_hidden = _run_rec(dec_rec, packed, None, self.en_residual, self.dec_num_rec_layers)
         dec_unp, _ = pad_packed_sequence(dec_out)
         dec_unp = self.dec_drop(dec_unp)
         n_t = dec_unp.shape[0]
-        score = dec_unp.reshape(n_t * b_sz, -1).mm(self.decoder_W) + self.decoder_b.view(1, -1)
+        score = dec_unp.reshape(n_t * b_sz, -1).mm(dec_W) + dec_b.view(1, -1)
         if compute_softmax:
             score = F.log_softmax(score, dim=1)
         return score.view(n_t, b_sz, self.vocab_size), (enc_hidden, dec_hidden)
@@ -275,18 +314,20 @@ class CharTranslator(nn.Module):
         dec_bsz = b_sz * n_samples
         ctxt_rep = ctxt.repeat(n_samples, 1)
         dec_inp = torch.cat([ctxt, targ_emb], dim=-1).repeat(n_samples, 1)
-        out, dec_hidden = _run_rec(self.dec_rec_layers, dec_inp.view(1, dec_bsz, -1), None, self.en_residual,
+        dec_rec, W, b = self._decoder(auths)
+        b = b.view(1, -1)
+        out, dec_hidden = _run_rec(dec_rec, dec_inp.view(1, dec_bsz, -1), None, self.en_residual,
                                    self.dec_num_rec_layers)
         p_rnn = out.view(dec_bsz, -1)
-        W, b = self.decoder_W, self.decoder_b.view(1, -1)
         char_out, samp_out = [], []
         gen_lens = torch.zeros(dec_bsz, dtype=torch.int32, device=dev)
         prev_done = torch.zeros(dec_bsz, dtype=torch.bool, device=dev)
         for _ in range(n_max):
             dec_out = p_rnn.mm(W) + b
             if soft_samples:
-                self.temp = temp
-                samp = gumbel_softmax_sample(dec_out * self.softmax_scale, temp, self.gumb_type, self.noise)
+                # learnt temperature: one tau >= 1 per row from the decoder state (char_translator.py:379)
+                self.temp = (F.softplus(p_rnn.mm(self.gumbel_W) + self.gumbel_b) + 1.) if self.learn_gumbel else temp
+                samp = gumbel_softmax_sample(dec_out * self.softmax_scale, self.temp, self.gumb_type, self.noise)
                 emb = samp.mm(self.char_emb.weight)
                 pred_c = samp.detach().argmax(dim=-1)
                 char_out.append(pred_c)
@@ -304,8 +345,7 @@ class CharTranslator(nn.Module):
             if bool(prev_done.all()):
                 break
             dec_inp = torch.cat([ctxt_rep, emb], dim=-1).view(1, dec_bsz, -1)
-            out, dec_hidden = _run_rec(self.dec_rec_layers, dec_inp, dec_hidden, self.en_residual,
-                                       self.dec_num_rec_layers)
+            out, dec_hidden = _run_rec(dec_rec, dec_inp, dec_hidden, self.en_residual, self.dec_num_rec_layers)
             p_rnn = out.view(dec_bsz, -1)
         return samp_out, gen_lens, char_out
 

@@ -9,8 +9,9 @@ from torch.nn.utils.rnn import pack_padded_sequence as pps
 
 from golden_util import Fixture, assert_close, assert_grads_close
 
-MLTRAIN = ['mltrain_plain', 'mltrain_res2', 'mltrain_deep2', 'mltrain_maxpool']
-GEN_SOFT = ['gen_soft_plain', 'gen_soft_res2']
+MLTRAIN = ['mltrain_plain', 'mltrain_res2', 'mltrain_deep2', 'mltrain_maxpool', 'mltrain_split', 'mltrain_noenc']
+GEN_SOFT = ['gen_soft_plain', 'gen_soft_res2', 'gen_soft_split', 'gen_soft_learntau', 'gen_soft_nsamp2_st0',
+            'gen_soft_advinp']
 CLF_LSTM = ['clf_lstm_mp0', 'clf_lstm_mp1', 'clf_lstm_mp2', 'clf_lstm_res']
 CLF_CNN = ['clf_cnn_234', 'clf_cnn_43', 'clf_cnn_3layer_res']
 ADV_STEP = ['adv_step_lstm', 'adv_step_cnn']
@@ -71,9 +72,15 @@ def run_gen_soft(impl, device, name, tol_out, tol_grad):
     m = _load(impl.CharTranslator(fx.params), fx.group('sd.'), device).train()
     m.set_noise(fx.noise_list(device))
     lens = fx.np('lens').tolist()
-    s, gl, co = m.forward_advers_gen(fx.t('inps'), lens, soft_samples=True, temp=float(fx.scalar('temp')),
+    kw, x = {}, fx.t('inps')
+    if 'n_samples' in fx and int(fx.scalar('n_samples')) != 1:
+        kw['n_samples'] = int(fx.scalar('n_samples'))
+    if 'soft' in fx:                        # soft (adv_inp) encoder input
+        x = fx.t('soft', device).requires_grad_(True)
+        kw['adv_inp'] = True
+    s, gl, co = m.forward_advers_gen(x, lens, soft_samples=True, temp=float(fx.scalar('temp')),
                                      n_max=int(fx.scalar('n_max')), end_c=int(fx.scalar('end_c')),
-                                     auths=fx.t('auths'))
+                                     auths=fx.t('auths'), **kw)
     samp = torch.stack(list(s), 0)
     chars = torch.stack(list(co), 0)
     assert samp.shape == fx.t('samp').shape, (samp.shape, fx.t('samp').shape)
@@ -83,6 +90,8 @@ def run_gen_soft(impl, device, name, tol_out, tol_grad):
     loss.backward()
     assert_close(samp, fx.t('samp'), tol_out, name + ' samples')
     assert_close(loss, fx.t('loss'), 10 * tol_out, name + ' loss')
+    if 'dsoft' in fx:
+        assert_close(x.grad, fx.t('dsoft'), tol_grad, name + ' dsoft')
     assert_grads_close(m.named_parameters(), fx.group('grad.'), tol_grad, name)
 
 

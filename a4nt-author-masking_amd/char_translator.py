@@ -300,6 +300,8 @@ class CharTranslator(nn.Module):
                 else:
                     samp, pred_c = ops.gumbel_dense(dec_out * self.softmax_scale, U, self.noise_seed, self._noise_step,
                                                     float(temp), bool(self.gumb_type))
+                    if not self.gumb_type:
+                        samp = _DropDoneRowGrads.apply(samp, prev_done)
                 self._noise_step += 1
                 emb = ops.linear_kn(samp, self.char_emb.weight)
                 char_out.append(pred_c)
@@ -346,6 +348,23 @@ class CharTranslator(nn.Module):
         self.train(was_training)
         n = int(gl.max().item())
         return co[:n]
+
+
+class _DropDoneRowGrads(torch.autograd.Function):
+    """Soft (non straight-through) samples are the softmax output itself, and the reference zeroes the
+    rows of finished sequences through .data (char_translator.py:384), i.e. in the tensor softmax's
+    backward reads: those rows get no gradient at all.  The row kernel keeps its own saved state, so the
+    same effect is applied to the incoming gradient here."""
+
+    @staticmethod
+    def forward(ctx, samp, done):
+        ctx.save_for_backward(done.clone())
+        return samp.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (done,) = ctx.saved_tensors
+        return g.masked_fill(done.view(-1, 1), 0.), None
 
 
 def _greedy_argmax(logits):

@@ -16,6 +16,6 @@ from .char_cnn import CharCNN                                             # noqa
 from .model_utils import get_classifier                                   # noqa: F401
 from .adv_step import (adv_forward_pass, d_update, g_update, make_optimizers, GradAllReducer,   # noqa: F401
                        synthetic_batch)
-from .ops import check_timeouts                                           # noqa: F401
+from .ops import check_timeouts, lstm_set_max_workgroups                  # noqa: F401
 
 load_library()

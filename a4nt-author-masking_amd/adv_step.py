@@ -19,7 +19,7 @@ from .gen_decode import SoftSamples
 
 def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all', maxlen=100, auths=None,
                      cycle_compute=False, append_symb=None, temp=0.5, cycle_loss_type='ml', targs=None,
-                     real_batch=None):
+                     real_batch=None, before_disc=None):
     """Returns (eval_logits [B,C] in input order, enc_out, samples (SoftSamples, generation order), gen_lens,
     char_outs[, cycle loss][, (real logits, real enc_out)]).
 
@@ -32,6 +32,8 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
         modelGen.train()
     samples, gen_lens, char_outs = modelGen.forward_advers_gen(
         inps, lens, soft_samples=True, end_c=end_c, n_max=maxlen, temp=temp, auths=1 - auths, compact=True)
+    if before_disc is not None:
+        before_disc()                   # e.g. the deferred discriminator step: the generation above did not need it
     gl_host = gen_lens.cpu()
     assert int(gl_host.min()) > 0
     len_sorted, sort_idx = gl_host.sort(dim=0, descending=True, stable=True)
@@ -82,12 +84,21 @@ def _set_requires_grad(model, flag):
 
 class GradAllReducer(object):
     """Batch data parallelism: average the gradients of `params` over all ranks (RCCL all-reduce on
-    GPU, gloo on CPU in the tests).  Gradients are flattened into a few large buckets (xGMI links
-    are per-peer: few large collectives beat many small ones) and reduced asynchronously, so the
-    caller can overlap the exchange with independent work and `wait()` before the optimizer step.
-    With world_size 1 (or no process group) it is a no-op."""
+    GPU, gloo on CPU in the tests).
 
-    def __init__(self, params, bucket_mb=32.0, group=None):
+    Gradients travel in a few large flat buckets (xGMI links are per-peer: few large collectives beat
+    many small ones).  With `overlap` (default) the exchange runs under the backward pass: `arm()`
+    before backward() installs post-accumulate hooks, a bucket's all-reduce is issued (async, on RCCL's
+    own stream) as soon as the last gradient of that bucket has been accumulated, and `wait()` only
+    has the tail to wait for.  Buckets are formed in the order the gradients became ready in the first
+    armed backward (rank 0's order is broadcast so that every rank uses the same layout) and are always
+    issued in index order, so every rank enqueues the same sequence of collectives.  Parameters whose
+    gradient never arrives in a backward (frozen, or unused by that pass) are skipped; that set is a
+    property of the graph and therefore the same on every rank.
+    With world_size 1 (or no process group) every method is a no-op."""
+
+    def __init__(self, params, bucket_mb=32.0, group=None, overlap=None):
+        import os
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -95,29 +106,95 @@ class GradAllReducer(object):
         self.world = dist.get_world_size(group) if self.on else 1
         self.params = [p for p in params]
         self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
+        if overlap is None:
+            overlap = os.environ.get('A4NT_DP_OVERLAP', '1') != '0'
+        self.overlap = bool(overlap) and self.on
         self._pending = []
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._hooks = None
+        self._armed = False
+        self._order = None          # parameter indices in gradient-ready order (learnt in the first armed backward)
+        self._seen = []
+        self._buckets_fixed = None  # list of lists of parameter indices
+        self._bucket_of = {}
+        self._ready = []
+        self._next = 0
 
-    def _buckets(self):
-        cur, n = [], 0
-        for p in self.params:
-            if p.grad is None:
-                continue
-            cur.append(p)
-            n += p.numel()
+    # -- bucket layout --------------------------------------------------------------------------
+    def _make_buckets(self, order):
+        buckets, cur, n = [], [], 0
+        for i in order:
+            cur.append(i)
+            n += self.params[i].numel()
             if n >= self.bucket_elems:
-                yield cur
+                buckets.append(cur)
                 cur, n = [], 0
         if cur:
-            yield cur
+            buckets.append(cur)
+        return buckets
 
+    def _fix_layout(self):
+        """After the first armed backward: adopt rank 0's ready order on every rank."""
+        seen = self._seen + [i for i in range(len(self.params)) if i not in set(self._seen)]
+        dev = self.params[0].device
+        order = torch.tensor(seen, dtype=torch.int64, device=dev)
+        self.dist.broadcast(order, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                            group=self.group)
+        self._order = [int(i) for i in order.tolist()]
+        self._buckets_fixed = self._make_buckets(self._order)
+        self._bucket_of = {i: b for b, idxs in enumerate(self._buckets_fixed) for i in idxs}
+
+    # -- overlapped path ------------------------------------------------------------------------
+    def arm(self):
+        """Call right before backward().  Installs the hooks once; (re)starts the per-step bookkeeping."""
+        if not self.overlap:
+            return
+        if self._hooks is None:
+            self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._armed = True
+        self._seen = []
+        self._next = 0
+        if self._buckets_fixed is not None:
+            self._ready = [0] * len(self._buckets_fixed)
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        i = self._index[id(p)]
+        self._seen.append(i)
+        if self._buckets_fixed is None:
+            return                       # first step: only learn the order; everything is reduced in wait()
+        b = self._bucket_of[i]
+        self._ready[b] += 1
+        # issue every complete bucket, strictly in index order
+        while self._next < len(self._buckets_fixed) and self._ready[self._next] == len(self._buckets_fixed[self._next]):
+            self._issue([self.params[j] for j in self._buckets_fixed[self._next]])
+            self._next += 1
+
+    def _issue(self, bucket):
+        bucket = [p for p in bucket if p.grad is not None]
+        if not bucket:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, flat, bucket))
+
+    # -- common ---------------------------------------------------------------------------------
     def launch(self):
-        """Start the all-reduce of every bucket (async); call after backward()."""
+        """Start the all-reduce of everything not issued yet (async); call after backward()."""
         if not self.on:
             return
-        for bucket in self._buckets():
-            flat = torch.cat([p.grad.reshape(-1) for p in bucket])
-            work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending.append((work, flat, bucket))
+        if self.overlap and self._armed:
+            self._armed = False
+            if self._buckets_fixed is None:
+                self._fix_layout()
+                self._next = 0
+            for b in range(self._next, len(self._buckets_fixed)):
+                self._issue([self.params[j] for j in self._buckets_fixed[b]])
+            self._next = len(self._buckets_fixed)
+            return
+        for idxs in self._make_buckets(range(len(self.params))):
+            self._issue([self.params[j] for j in idxs])
 
     def wait(self):
         """Finish the exchange and write the averaged gradients back."""
@@ -138,10 +215,24 @@ class GradAllReducer(object):
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def token_weight(self, n_local):
+        """Factor for a per-token mean loss so that the rank-averaged gradient equals the gradient of the
+        mean over the GLOBAL token count (ragged batches: ranks hold different numbers of valid tokens)."""
+        if not self.on:
+            return 1.0
+        t = torch.tensor(float(n_local), device=self.params[0].device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return (float(n_local) * self.world) / t          # stays on the device: no host sync
+
 
 def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c, maxlen, temp, step=True,
-             reducer=None):
-    """One discriminator update (:433-547): BCE(real, 1) + BCE(fake, 0) on column 1 - c_aid, RMSprop, no clipping."""
+             reducer=None, defer=False):
+    """One discriminator update (:433-547): BCE(real, 1) + BCE(fake, 0) on column 1 - c_aid, RMSprop, no clipping.
+
+    defer=True: return with the gradient exchange in flight and the optimizer step not yet applied;
+    result['finish']() completes both.  g_update(before_disc=finish) calls it right before the
+    generator update first touches the discriminator, so the exchange and the step's host work overlap
+    the generator's free-running generation (which does not read the discriminator)."""
     _set_requires_grad(modelEval, True)
     _set_requires_grad(modelGen, False)
     inps, targs, auths, lens = src_batch
@@ -155,19 +246,32 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
     gen_aid_out = outs[0][:, targ_aid]
     loss = (F.binary_cross_entropy_with_logits(real_aid_out, torch.ones_like(real_aid_out)) +
             F.binary_cross_entropy_with_logits(gen_aid_out, torch.zeros_like(gen_aid_out)))
+    if reducer is not None:
+        reducer.arm()
     loss.backward()
     if reducer is not None:
         reducer.launch()
-        reducer.wait()
-    if step:
-        optimEval.step()
-    return {'loss': loss.detach(), 'fake_logits': outs[0].detach(), 'real_logits': eval_out_gt[0].detach(),
-            'gen_lens': outs[3], 'char_outs': outs[4]}
+
+    def finish():
+        if reducer is not None:
+            reducer.wait()
+        if step:
+            optimEval.step()
+
+    res = {'loss': loss.detach(), 'fake_logits': outs[0].detach(), 'real_logits': eval_out_gt[0].detach(),
+           'gen_lens': outs[3], 'char_outs': outs[4]}
+    if defer:
+        res['finish'] = finish
+    else:
+        finish()
+    return res
 
 
 def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, append_symb, cycle_loss_type='ml',
-             cycle_loss_w=1.0, grad_clip=10.0, step=True, reducer=None):
-    """One generator update (:553-735): 5*BCE(fake, 1) + w * CE reconstruction, clip_grad_norm, RMSprop."""
+             cycle_loss_w=1.0, grad_clip=10.0, step=True, reducer=None, before_disc=None):
+    """One generator update (:553-735): 5*BCE(fake, 1) + w * CE reconstruction, clip_grad_norm, RMSprop.
+    before_disc: callable run after the generation forward and before the discriminator is used
+    (the deferred tail of d_update)."""
     _set_requires_grad(modelEval, False)
     _set_requires_grad(modelGen, True)
     optimGen.zero_grad()
@@ -175,9 +279,10 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
     inps, targs, auths, lens = batch
     outs = adv_forward_pass(modelGen, modelEval, inps, lens, end_c=end_c, maxlen=maxlen, auths=auths,
                             cycle_compute=(cycle_loss_type is not None), append_symb=append_symb, temp=temp,
-                            cycle_loss_type=cycle_loss_type, targs=targs)
+                            cycle_loss_type=cycle_loss_type, targs=targs, before_disc=before_disc)
     if cycle_loss_type == 'ml':
-        cyc_loss = cycle_loss_w * outs[-1]
+        w_tok = reducer.token_weight(sum(int(l) for l in lens)) if reducer is not None else 1.0
+        cyc_loss = cycle_loss_w * w_tok * outs[-1]
     else:
         cyc_loss = torch.zeros((), device=outs[0].device)
     targ_aid = 1 - c_aid
@@ -185,6 +290,8 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
     loss_gan = 5.0 * F.binary_cross_entropy_with_logits(gen_aid_out, torch.ones_like(gen_aid_out))
     err = (gen_aid_out.detach() > 0.).float().mean()
     loss_tot = loss_gan + cyc_loss
+    if reducer is not None:
+        reducer.arm()
     loss_tot.backward()
     if reducer is not None:
         reducer.launch()

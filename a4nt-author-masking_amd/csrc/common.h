@@ -60,7 +60,7 @@ __device__ __forceinline__ void st_flag(unsigned* p, unsigned v) {
 
 // Bounded wait: returns false when the counter did not reach `target` within the spin budget or
 // another workgroup already raised the timeout word.  Called by ONE lane.
-#define A4NT_SPIN_LIMIT (1u << 22)
+#define A4NT_SPIN_LIMIT (1u << 24)
 __device__ __forceinline__ bool wait_ge(const unsigned* ctr, unsigned target, unsigned* timeout_word) {
     for (unsigned spins = 0;; ++spins) {
         if (ld_flag(ctr) >= target) return true;

@@ -219,6 +219,13 @@ def _lstm_ws(dev, B, H, backward):
     return _ws[key]
 
 
+def lstm_set_max_workgroups(n):
+    """256: one persistent-sweep workgroup per CU (leaves register space for kernels of other streams,
+    e.g. RCCL under data parallelism); 512 (default): two per CU where the geometry allows it."""
+    check(_lib.load().a4nt_lstm_set_max_workgroups(int(n)), 'a4nt_lstm_set_max_workgroups')
+    _ws.clear()                 # geometry changed: workspaces are re-made on next use
+
+
 def check_timeouts():
     """Raise if any persistent sweep so far gave up on an inter-workgroup wait (host sync)."""
     for sync, g in _sync_blocks:

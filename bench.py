@@ -55,9 +55,12 @@ def adv_step(impl, G, D, optG, optD, batches, it, batch, reducers):
     c_aid = it % 2
     mk = lambda b, a: (b[0], b[1], torch.full((batch,), a, dtype=torch.long), b[2])
     src, tgt, gb = batches[(3 * it) % len(batches)], batches[(3 * it + 1) % len(batches)], batches[(3 * it + 2) % len(batches)]
-    rd = impl.d_update(G, D, optD, mk(src, c_aid), mk(tgt, 1 - c_aid), c_aid, -1, T, 0.5, reducer=reducers[1])
+    # the discriminator's gradient exchange + optimizer step are deferred into the generator update, where they
+    # overlap the free-running generation (which does not read the discriminator)
+    rd = impl.d_update(G, D, optD, mk(src, c_aid), mk(tgt, 1 - c_aid), c_aid, -1, T, 0.5, reducer=reducers[1],
+                       defer=True)
     rg = impl.g_update(G, D, optG, mk(gb, c_aid), c_aid, -1, T, 0.5, 2, cycle_loss_type='ml', cycle_loss_w=1.0,
-                       grad_clip=10.0, reducer=reducers[0])
+                       grad_clip=10.0, reducer=reducers[0], before_disc=rd.pop('finish'))
     return rd, rg
 
 
@@ -133,6 +136,9 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     import a4nt_amd as impl
     from a4nt_amd import ops
+    if world > 1:
+        # leave half of every CU's registers to the RCCL kernels that run beside the persistent LSTM sweeps
+        impl.lstm_set_max_workgroups(256)
 
     torch.manual_seed(0)
     G = impl.CharTranslator(gen_params(args.batch))

@@ -26,7 +26,7 @@ def _data():
     return x, y
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, overlap):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -36,20 +36,27 @@ def _worker(rank, world, port, out_q):
     m = oracle.CharLstm(EP)
     x, y = _data()
     sh = slice(rank * B // world, (rank + 1) * B // world)
-    logits, _ = m.forward_classify(x[:, sh], lens=[T] * (B // world))
-    F.cross_entropy(logits, y[sh]).backward()
-    red = GradAllReducer(list(m.parameters()), bucket_mb=0.001)     # tiny buckets: several collectives in flight
-    red.launch()
-    red.wait()
+    red = GradAllReducer(list(m.parameters()), bucket_mb=0.001, overlap=overlap)   # tiny buckets: several in flight
+    issued_early = []
+    for it in range(3):         # overlap: step 0 learns the gradient-ready order, steps 1-2 reduce under backward()
+        m.zero_grad()
+        logits, _ = m.forward_classify(x[:, sh], lens=[T] * (B // world))
+        red.arm()
+        F.cross_entropy(logits, y[sh]).backward()
+        issued_early.append(len(red._pending))
+        red.launch()
+        red.wait()
     cnt = red.all_reduce_scalars(torch.tensor([1.0 + rank, 10.0]))
+    w_tok = float(red.token_weight(10 if rank == 0 else 30))
     if rank == 0:
-        out_q.put(({n: p.grad.clone() for n, p in m.named_parameters()}, cnt))
+        out_q.put(({n: p.grad.clone() for n, p in m.named_parameters()}, cnt, issued_early, w_tok))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(120)
-def test_two_ranks_equal_one_big_batch():
+@pytest.mark.parametrize('overlap', [False, True])
+def test_two_ranks_equal_one_big_batch(overlap):
     import oracle
     torch.manual_seed(0)
     ref = oracle.CharLstm(EP)
@@ -59,14 +66,21 @@ def test_two_ranks_equal_one_big_batch():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port += 7 * int(overlap)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
-    grads, cnt = q.get(timeout=100)
+    grads, cnt, issued_early, w_tok = q.get(timeout=100)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert torch.allclose(cnt, torch.tensor([3.0, 20.0]))
+    assert abs(w_tok - 10 * 2 / 40.0) < 1e-6          # rank 0 holds 10 of the 40 valid tokens
+    if overlap:
+        # nothing can be issued while the order is being learnt; afterwards most buckets go out inside backward()
+        assert issued_early[0] == 0 and issued_early[1] > 0 and issued_early[2] > 0, issued_early
+    else:
+        assert issued_early == [0, 0, 0]
     for n, p in ref.named_parameters():
         assert torch.allclose(grads[n], p.grad, rtol=1e-5, atol=1e-7), n
 

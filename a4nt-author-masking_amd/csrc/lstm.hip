@@ -177,25 +177,29 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[gt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 af[NJ][MT];
+        // A blocks are pulled CHF at a time so that H = 1024 (16 blocks per wave, 256 weight registers) still fits
+        constexpr int CHF = (NJ * MT > 16) ? (16 / MT) : NJ;
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
+        for (int jc = 0; jc < NJ / CHF; ++jc) {
+            f32x4 af[CHF][MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const long long blk = ((long long)(par_r * a.G + g) * a.NW + (w * nj + jj)) * MT + mt;
-                af[jj][mt] = ld16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + fq * 4) * 4));
-            }
-        STAMP_WAITV();
-        STAMP(1);
+            for (int j8 = 0; j8 < CHF; ++j8)
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
+                for (int mt = 0; mt < MT; ++mt) {
+                    const long long blk = ((long long)(par_r * a.G + g) * a.NW + (w * nj + jc * CHF + j8)) * MT + mt;
+                    af[j8][mt] = ld16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + fq * 4) * 4));
+                }
+            if (jc == NJ / CHF - 1) { STAMP_WAITV(); STAMP(1); }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j8 = 0; j8 < CHF; ++j8)
 #pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[gt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[jj][mt][i], wreg[jj][gt][i], acc[gt][mt], 0, 0, 0);
+                    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[gt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j8][mt][i], wreg[jc * CHF + j8][gt][i], acc[gt][mt], 0, 0, 0);
+        }
         // (e) partial gate tiles -> LDS   (C layout: col = lane&15, row = 4*(lane>>4) + reg)
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
@@ -501,13 +505,16 @@ static int pick_mt(int B, int NW, int* G) {
         else if (mt == 4 && nj == 1) hipLaunchKernelGGL((KERNEL<4, 1>), grid, block, 0, s, a);                    \
         else if (mt == 4 && nj == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, block, 0, s, a);                    \
         else if (mt == 4 && nj == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, block, 0, s, a);                    \
-        else hipLaunchKernelGGL((KERNEL<4, 8>), grid, block, 0, s, a);                                            \
+        else if (mt == 4 && nj == 8) hipLaunchKernelGGL((KERNEL<4, 8>), grid, block, 0, s, a);                    \
+        else if (mt == 1 && nj == 16) hipLaunchKernelGGL((KERNEL<1, 16>), grid, block, 0, s, a);                  \
+        else if (mt == 2 && nj == 16) hipLaunchKernelGGL((KERNEL<2, 16>), grid, block, 0, s, a);                  \
+        else hipLaunchKernelGGL((KERNEL<4, 16>), grid, block, 0, s, a);                                           \
     } while (0)
 
-static bool bad_h(int H) { return !(H == 64 || H == 128 || H == 256 || H == 512); }
+static bool bad_h(int H) { return !(H == 64 || H == 128 || H == 256 || H == 512 || H == 1024); }
 
 extern "C" int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out) {
-    if (B <= 0 || bad_h(H)) { a4nt_set_error("a4nt_lstm: H must be 64, 128, 256 or 512 (multiple of 64 kernels are instantiated for these), got H=%d B=%d", H, B); return A4NT_ERR_ARG; }
+    if (B <= 0 || bad_h(H)) { a4nt_set_error("a4nt_lstm: H must be 64, 128, 256, 512 or 1024 (the kernels are instantiated for these), got H=%d B=%d", H, B); return A4NT_ERR_ARG; }
     int G = 0;
     const int mt = pick_mt(B, H / 16, &G);
     if (!mt) { a4nt_set_error("a4nt_lstm: batch %d too large for one sweep at H=%d (max %d rows)", B, H, 64 * (256 / (H / 16))); return A4NT_ERR_ARG; }

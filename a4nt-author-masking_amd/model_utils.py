@@ -110,6 +110,6 @@ def get_classifier(params):
 
 
 def check_hidden(h, what):
-    if h not in (64, 128, 256, 512):
+    if h not in (64, 128, 256, 512, 1024):
         raise ops.A4NTError('%s = %d: the gfx950 persistent LSTM kernels are instantiated for hidden sizes '
-                            '64, 128, 256 and 512' % (what, h))
+                            '64, 128, 256, 512 and 1024' % (what, h))

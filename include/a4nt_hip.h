@@ -42,7 +42,7 @@ int a4nt_sgemm(int transA, int transB, int M, int N, int K, const float* A, int 
 int a4nt_sgemm_tile(int M, int N, int ksplit);
 
 /* Geometry of the persistent LSTM sweeps for a batch of B rows and hidden size H
- * (H multiple of 64, 64..512): rows per group = 16*mt, groups*(H/16) workgroups <= 256. */
+ * (H in {64, 128, 256, 512, 1024}): rows per group = 16*mt, groups*(H/16) workgroups <= 256. */
 int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out);
 /* 256 (default: one workgroup per CU) or 512 (two per CU; needs the GPU to itself). */
 int a4nt_lstm_set_max_workgroups(int n);

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import a4nt_amd
 from a4nt_amd import ops, _lib
 lib = _lib.load()
-T, H = 100, 512
+T = 100
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 for maxwg in (256, 512):
     lib.a4nt_lstm_set_max_workgroups(maxwg)
     ops._ws.clear()

@@ -15,8 +15,9 @@
 // sweep), emit h_t / the saved activations, and publish the workgroup's 16x16 h block for the
 // next step.  Only the NW workgroups of one group synchronise with each other; groups never do.
 //
-// Backward is the mirror image: workgroup j owns dh columns [16j, 16j+16), wave w owns gate w's
-// H rows of W_hh (K = 4H split over the 4 waves), the exchanged quantity is dgates_t.
+// Backward: workgroup j turns the dgates of its own 16 units into a partial dh_{t-1} over all H
+// columns with its 64 rows of W_hh, and the partials are reduce-scattered between the workgroups
+// (see lstm_bwd_kernel).
 //
 // Sequences of different lengths: a row simply freezes (state kept, output zero, gradient zero)
 // once t >= len[row]; no sorting or packing is needed by the kernels.
@@ -286,40 +287,46 @@ struct LstmBwdArgs {
     const float* dhN; const float* dcN;   // [B][H] or null
     float* dgates;          // [T][B][4H] (may alias gates)
     float* dh0; float* dc0; // [B][H] or null
-    float* gxch;            // exchange [2][G][4][NW][MT][256]
+    float* gxch;            // exchange [2][G][NW consumers][NW producers][MT][256]
     unsigned* sync;
     int need_dh0;           // run the recurrent product of the last step too
 };
 
 template <int MT, int NJ>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float part[4][MT][16 * 20];
-    __shared__ __attribute__((aligned(16))) float stage[4][MT][256];
+    // Workgroup j of a row group owns hidden units [16j, 16j+16): it computes dgates_t for those units
+    // (64 of the 4H gate rows) and multiplies them, straight from LDS, with ITS 64 rows of W_hh, which
+    // gives a partial dh_{t-1} for ALL H columns; the partials are exchanged as 16x16 blocks and every
+    // workgroup sums the NW blocks of its own 16 columns (a reduce-scatter per step).  The payload per
+    // step is H floats per row in each direction, as in the forward sweep (an all-gather of dgates would
+    // move 4H).  Wave w owns output columns [w*H/4, (w+1)*H/4).
+    __shared__ __attribute__((aligned(16))) float sA[MT][16 * 68];      // dgates tile [row][gate*16 + unit]
+    __shared__ __attribute__((aligned(16))) float red[4][MT][16 * 20];  // per-wave partial sums [col][row]
     __shared__ int s_ok;
 
     const int g = blockIdx.x % a.G, j = blockIdx.x / a.G;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H = a.H, H4 = 4 * a.H;
-    constexpr int njb = 4 * NJ;             // 16-row k blocks per gate (H = 64*NJ)
     const int u0 = 16 * j;
     const int r0 = g * 16 * MT;
     const int fr = lane & 15, fq = lane >> 4;
     const int crow = tid >> 4, cunit = tid & 15;
 
-    // wave w: rows [w*H, (w+1)*H) of W_hh (gate w), columns u0..u0+15
-    f32x4 wreg[njb];
+    // B operands: wreg[ct][gate][i] (lane n = fr, quad fq) = W_hh[gate*H + u0 + 4*fq + i][w*H/4 + 16*ct + fr]
+    // (the k order inside a gate's 16 units is permuted the same way on the A side)
+    float wreg[NJ][4][4];
 #pragma unroll
-    for (int jj = 0; jj < njb; ++jj) {
-        const float* p = a.whh + (long long)(w * H + 16 * jj + 4 * fq) * H + u0 + fr;
-        f32x4 t;
-        t.x = p[0]; t.y = p[H]; t.z = p[2 * H]; t.w = p[3 * H];
-        wreg[jj] = t;
-    }
+    for (int ct = 0; ct < NJ; ++ct)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                wreg[ct][gt][i] = a.whh[(long long)(gt * H + u0 + 4 * fq + i) * H + w * (H >> 2) + 16 * ct + fr];
 
     unsigned* ctr = a.sync + 32 * g;
     unsigned* tmo = a.sync + 32 * a.G;
     const unsigned blk_bytes = 256 * 4;
-    const long long x_par = (long long)a.G * 4 * a.NW * MT * 256;
+    const long long x_par = (long long)a.G * a.NW * a.NW * MT * 256;    // floats per parity
     __amdgpu_buffer_rsrc_t rs = make_rsrc(a.gxch, (unsigned)(2 * x_par * 4));
 
     float dh_rec[MT], dc_next[MT];
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
                 }
             }
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) { stage[gt][mt][crow * 16 + cunit] = dp[gt]; dpo[mt][gt] = dp[gt]; }
+            for (int gt = 0; gt < 4; ++gt) { sA[mt][crow * 68 + gt * 16 + cunit] = dp[gt]; dpo[mt][gt] = dp[gt]; }
         }
         if (t == 0 && !a.need_dh0) {
             // last step: nothing to exchange, just emit dgates_0
@@ -401,12 +408,39 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
             break;
         }
         __syncthreads();
-        // (b) publish dgates_t: wave w writes the blocks of gate w
+        // (b) partial dh_{t-1}[:, this wave's columns] = dgates_t[:, own 64] * W_hh[own 64 rows, those columns]
+        // column tiles go CHB at a time (bounds the accumulator registers at H = 1024 / MT = 4); the A
+        // fragments are re-read from LDS per gate and chunk
+        constexpr int CHB = (NJ * MT > 16) ? ((NJ == 16 ? 8 : 16) / MT) : NJ;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&stage[w][mt][4 * lane]);
-            const long long blk = ((((long long)par * a.G + g) * 4 + w) * a.NW + j) * MT + mt;
-            st16_sc1(rs, (unsigned)(blk * blk_bytes + lane * 16), v);
+        for (int cc = 0; cc < NJ / CHB; ++cc) {
+            f32x4 acc[CHB][MT];
+#pragma unroll
+            for (int c8 = 0; c8 < CHB; ++c8)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[c8][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) {
+                f32x4 af[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(&sA[mt][fr * 68 + gt * 16 + 4 * fq]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c8 = 0; c8 < CHB; ++c8)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[c8][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][i], wreg[cc * CHB + c8][gt][i], acc[c8][mt], 0, 0, 0);
+            }
+            // publish: block (consumer c, producer j, mt), layout [col][row] (C fragment order: one 1 KiB store per wave)
+#pragma unroll
+            for (int c8 = 0; c8 < CHB; ++c8)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int c = w * NJ + cc * CHB + c8;
+                    const long long blk = ((((long long)par * a.G + g) * a.NW + c) * a.NW + j) * MT + mt;
+                    st16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + 4 * fq) * 4), acc[c8][mt]);
+                }
         }
         drain_vmem();
         __syncthreads();
@@ -423,41 +457,38 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
         if (tid == 0) s_ok = wait_ge(ctr, (unsigned)(a.NW * (s + 1)), tmo) ? 1 : 0;
         __syncthreads();
         if (!s_ok) break;
-        // (c) dh_rec[:, u0..u0+15] = dgates_t[:, gate w rows] * W_hh[gate w rows, u0..u0+15], K split over waves
-        f32x4 acc[MT][2];
+        // (c) sum the NW partial blocks of this workgroup's 16 columns: wave w takes producers [w*NJ, (w+1)*NJ)
+        f32x4 ps[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = acc[mt][0]; }
-        constexpr int CH = njb < 8 ? njb : 8;       // blocks loaded per chunk
+        for (int mt = 0; mt < MT; ++mt) ps[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jc = 0; jc < njb / CH; ++jc) {
-            f32x4 af[CH][MT];
+        for (int cc = 0; cc < NJ / CHB; ++cc) {
+            f32x4 ld[CHB][MT];
 #pragma unroll
-            for (int j8 = 0; j8 < CH; ++j8)
+            for (int p8 = 0; p8 < CHB; ++p8)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int jj = jc * CH + j8;
-                    const long long blk = ((((long long)par * a.G + g) * 4 + w) * a.NW + jj) * MT + mt;
-                    af[j8][mt] = ld16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + fq * 4) * 4));
+                    const long long blk = ((((long long)par * a.G + g) * a.NW + j) * a.NW + (w * NJ + cc * CHB + p8)) * MT + mt;
+                    ld[p8][mt] = ld16_sc1(rs, (unsigned)(blk * blk_bytes + lane * 16));
                 }
 #pragma unroll
-            for (int j8 = 0; j8 < CH; ++j8)
+            for (int p8 = 0; p8 < CHB; ++p8)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][j8 & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j8][mt][i], wreg[jc * CH + j8][i], acc[mt][j8 & 1], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) {
+                    ps[mt].x += ld[p8][mt].x; ps[mt].y += ld[p8][mt].y; ps[mt].z += ld[p8][mt].z; ps[mt].w += ld[p8][mt].w;
+                }
         }
+        // lane l holds column l>>2, rows 4*(l&3)..+3
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) part[w][mt][(4 * fq + i) * 20 + fr] = acc[mt][0][i] + acc[mt][1][i];
+            *reinterpret_cast<f32x4*>(&red[w][mt][(lane >> 2) * 20 + 4 * (lane & 3)]) = ps[mt];
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int o = crow * 20 + cunit;
-            dh_rec[mt] = (part[0][mt][o] + part[1][mt][o]) + (part[2][mt][o] + part[3][mt][o]);
+            const int o = cunit * 20 + crow;
+            dh_rec[mt] = (red[0][mt][o] + red[1][mt][o]) + (red[2][mt][o] + red[3][mt][o]);
         }
-        // the next iteration's barrier after (a) orders these LDS reads before part[] is rewritten
+        // the next iteration's barrier after (a) orders these LDS reads before red[] / sA[] are rewritten
     }
 
 #pragma unroll
@@ -527,7 +558,7 @@ extern "C" long long a4nt_lstm_xch_floats(int B, int H, int backward) {
     int mt, G;
     if (a4nt_lstm_geometry(B, H, &mt, &G) != A4NT_OK) return -1;
     const long long per = (long long)G * (H / 16) * mt * 256;
-    return 2 * per * (backward ? 4 : 1);
+    return 2 * per * (backward ? (H / 16) : 1);
 }
 extern "C" int a4nt_lstm_sync_words(int B, int H) {
     int mt, G;

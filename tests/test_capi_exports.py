@@ -42,12 +42,14 @@ def test_argument_errors_without_gpu():
     assert (mt.value, g.value) == (4, 8)
     assert lib.a4nt_lstm_geometry(5, 64, ctypes.byref(mt), ctypes.byref(g)) == 0
     assert (mt.value, g.value) == (1, 1)
-    assert lib.a4nt_lstm_geometry(8, 100, ctypes.byref(mt), ctypes.byref(g)) == 1      # H not a multiple of 64
-    assert b'multiple of 64' in lib.a4nt_last_error()
+    assert lib.a4nt_lstm_geometry(8, 100, ctypes.byref(mt), ctypes.byref(g)) == 1      # H not instantiated
+    assert b'H must be 64, 128, 256, 512 or 1024' in lib.a4nt_last_error()
+    assert lib.a4nt_lstm_geometry(256, 1024, ctypes.byref(mt), ctypes.byref(g)) == 0
+    assert (mt.value, g.value) == (4, 4)
     assert lib.a4nt_lstm_geometry(4096, 512, ctypes.byref(mt), ctypes.byref(g)) == 1   # batch too large
     assert lib.a4nt_version() == 100
     assert lib.a4nt_lstm_xch_floats(128, 512, 0) == 2 * 8 * 32 * 256
-    assert lib.a4nt_lstm_xch_floats(128, 512, 1) == 2 * 8 * 32 * 256 * 4
+    assert lib.a4nt_lstm_xch_floats(128, 512, 1) == 2 * 8 * 32 * 256 * 32     # [parity][group][consumer][producer] blocks
     assert lib.a4nt_lstm_sync_words(128, 512) == 32 * 8 + 32
 
 

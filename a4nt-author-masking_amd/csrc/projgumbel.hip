@@ -2,21 +2,33 @@
 // (reference models/char_translator.py:377-392: dec_out = p_rnn.mm(W)+b; gumbel_softmax_sample;
 //  argmax; done / gen_lens bookkeeping).
 //
-// One decoder step multiplies only B <= 128 rows by the [H,V] projection, so the generic 64x64 /
-// 128x128 tilings leave the chip badly balanced (314 or 79 workgroups on 256 CUs).  Here every
-// workgroup takes ALL rows and a 16*NT-column strip of the vocabulary (209 strips at V = 10001),
-// runs the contraction on v_mfma_f32_16x16x4_f32 and finishes the sampling in the epilogue:
+// One decoder step multiplies only B <= 128 rows by the [H,V] projection: 8 x 626 MFMA tiles of 16x16
+// for 1024 SIMDs.  LDS-staged tilings (the generic 64x64 / 128x128 kernels, and three LDS versions of
+// this one: 128x48 and 32x64 tiles with 32-deep k-tiles, 64x80 with 128-deep chunks) all took 27-33 us
+// for the 1.3 GFLOP whatever the tile shape or occupancy: with so few rows every wave's critical path
+// is load -> LDS -> barrier -> ds_read -> MFMA -> epilogue, and nothing overlaps it.
+// This version has no LDS and no barrier.  Every WAVE owns a 16-row x 80-column output tile
+// (8 x 126 = 1008 waves, one per SIMD: 98 % of the 1024 SIMDs carry exactly five MFMA tiles) and feeds
+// v_mfma_f32_16x16x4_f32 straight from registers:
+//   A (h rows):   lane (row m, quad q) loads h[m][16j+4q .. +3] with one dwordx4; register i is the A operand
+//                 of k-step i, whose k set is therefore {16j+4q+i}: a permutation of the block's 16 k's;
+//   B (W [K][N]): for that k (= 16j+4q+i) lane (n, q) loads W[k][c0+5n .. 5n+4] (dwordx4 + dword; the 16 lanes
+//                 of a quad cover 320 contiguous bytes); register c is the B operand of column tile c, i.e.
+//                 column tile c holds the columns {c0 + 5n + c}: a strided column set, which the epilogue
+//                 simply accounts for.
+// Loads run eight 16-k blocks ahead in a register ring (the W stream comes from HBM / Infinity Cache).
+// The sampling is finished in the epilogue:
 //     z = scale*(h W + b) + gumbel(u)                      (greedy: z = h W + b)
 // softmax((log_softmax(x)+g)/tau) == softmax(z/tau) (shift invariance), so the row statistics the
-// sampler needs are max z, arg max z and sum exp((z - max)/tau).  Each strip emits those three per
-// row; a tiny finalize kernel merges the strips (online-softmax merge), derives the straight-through
-// value and updates done / gen_lens.  z is stored once (saved for the backward pass); the logits
-// never make a round trip through HBM.
+// sampler needs are max z, arg max z and sum exp((z - max)/tau).  Each wave emits those three per row
+// for its 80-column strip; a tiny finalize kernel merges the strips (online-softmax merge), derives the
+// straight-through value and updates done / gen_lens.  z is stored once (saved for the backward pass);
+// the logits never make a round trip through HBM.
 #include "gemm_stage.h"
 
-#define PG_BM 128
-#define PG_BK 32
-#define PG_BC 64          // staged B columns (NT <= 4)
+#define PG_BM 64          // rows per workgroup: wave w owns rows [16w, 16w+16)
+#define PG_BC 80          // strip width: five 16-column MFMA tiles per wave
+#define PG_DEPTH 8        // 16-k blocks in flight per wave
 
 struct ProjGumbelArgs {
     const float* h; int ldh;
@@ -45,150 +57,138 @@ __device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-template <int NT>
-__device__ __forceinline__ void pg_mma(const float* as, const float* bs, int w, int fr, int fq, f32x4 (&acc)[2][NT]) {
+struct PgBlock {            // operands of one 16-k block
+    f32x4 a;                // A: k-steps 0..3
+    f32x4 b4[4];            // B of k-step i: column tiles 0..3
+    float b1[4];            //                column tile 4
+};
+
+__device__ __forceinline__ void pg_load(PgBlock& blk, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned aoff,
+                                        unsigned boff, unsigned ldw_bytes, int kb, bool on) {
+    // kb: first k of the block; `on` false (past the end of K) loads nothing that is used
+    blk.a = bl4(ra, on ? aoff + (unsigned)kb * 4u : OOB);
 #pragma unroll
-    for (int kk = 0; kk < PG_BK; kk += 4) {
-        float a[2], b[NT];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = as[(kk + fq) * (PG_BM + LPAD) + (2 * w + i) * 16 + fr];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = bs[(kk + fq) * (PG_BC + LPAD) + nt * 16 + fr];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[nt], acc[i][nt], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+        const unsigned bo = on ? boff + (unsigned)(kb + i) * ldw_bytes : OOB;
+        blk.b4[i] = bl4(rb, bo);
+        blk.b1[i] = bl1(rb, on ? bo + 16u : OOB);
     }
 }
 
-template <int NT, bool EB>
-__device__ __forceinline__ void pg_kloop(const ProjGumbelArgs& a, int m0, int c0, float (*As)[PG_BK * (PG_BM + LPAD)],
-                                         float (*Bs)[PG_BK * (PG_BC + LPAD)], int w, int fr, int fq, f32x4 (&acc)[2][NT]) {
-    constexpr int PF = 2;
-    StageKC<PG_BM, PG_BK> sa[PF];
-    StageMC<PG_BC, PG_BK> sb[PF];
-    const int nk = a.K / PG_BK;
-    const int kfull = nk * PG_BK;
+__device__ __forceinline__ void pg_mma(const PgBlock& blk, f32x4 (&acc)[5]) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        sa[u].template load<false>(a.h, a.ldh, m0, a.M, u * PG_BK, kfull);
-        sb[u].template load<EB>(a.W, a.ldw, c0, a.N, u * PG_BK, kfull);
-    }
-    if (nk > 0) { sa[0].store(As[0]); sb[0].store(Bs[0]); }
-    __syncthreads();
-    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int kt = kt0 + u;
-            if (kt >= nk) break;
-            const int cur = kt & 1;
-            sa[u].template load<false>(a.h, a.ldh, m0, a.M, (kt + PF) * PG_BK, kfull);
-            sb[u].template load<EB>(a.W, a.ldw, c0, a.N, (kt + PF) * PG_BK, kfull);
-            pg_mma<NT>(As[cur], Bs[cur], w, fr, fq, acc);
-            sa[(u + 1) % PF].store(As[cur ^ 1]);
-            sb[(u + 1) % PF].store(Bs[cur ^ 1]);
-            __syncthreads();
-        }
-    }
-    if (kfull < a.K) {                       // partial last K tile
-        sa[0].template load<true>(a.h, a.ldh, m0, a.M, kfull, a.K);
-        sb[0].template load<true>(a.W, a.ldw, c0, a.N, kfull, a.K);
-        sa[0].store(As[0]); sb[0].store(Bs[0]);
-        __syncthreads();
-        pg_mma<NT>(As[0], Bs[0], w, fr, fq, acc);
+    for (int i = 0; i < 4; ++i) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[i], blk.b4[i].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[i], blk.b4[i].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[i], blk.b4[i].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[i], blk.b4[i].w, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[i], blk.b1[i], acc[4], 0, 0, 0);
     }
 }
 
-template <int NT>
 __global__ __launch_bounds__(256) void proj_gumbel_kernel(ProjGumbelArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[2][PG_BK * (PG_BM + LPAD)];
-    __shared__ __attribute__((aligned(16))) float Bs[2][PG_BK * (PG_BC + LPAD)];
-    constexpr int SW = 16 * NT;
-    const int strip = blockIdx.x;
-    const int m0 = blockIdx.y * PG_BM, c0 = strip * SW;
+    // 1-D grid; the row blocks of one strip sit 8 apart in block id (id % 8 = strip % 8), so under round-robin
+    // placement they land on the same XCD and share the strip of W in that XCD's L2 (speed only)
+    const int nrb = (a.M + PG_BM - 1) / PG_BM;
+    const int grp = blockIdx.x / (8 * nrb), rem = blockIdx.x % (8 * nrb);
+    const int strip = grp * 8 + (rem & 7), rblk = rem >> 3;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+    const int m0 = rblk * PG_BM + 16 * w, c0 = strip * PG_BC;
+    if (strip >= a.nstrips || m0 >= a.M) return;             // no barriers below
 
-    f32x4 acc[2][NT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[i][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A: row m0+fr (clamped), k offset 4*fq inside a block.  B: columns c0 + 5*fr .. +4, k row 4*fq + i.
+    const int arow = min(m0 + fr, a.M - 1);
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(a.h, clamp_bytes(((long long)(a.M - 1) * a.ldh + a.K) * 4));
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(a.W, clamp_bytes(((long long)(a.K - 1) * a.ldw + a.N) * 4));
+    const unsigned aoff = (unsigned)(arow * a.ldh + 4 * fq) * 4u;
+    const unsigned ldw_bytes = (unsigned)a.ldw * 4u;
+    const unsigned boff = (unsigned)(4 * fq) * ldw_bytes + (unsigned)(c0 + 5 * fr) * 4u;
 
-    if (a.N - c0 >= PG_BC) pg_kloop<NT, false>(a, m0, c0, As, Bs, w, fr, fq, acc);
-    else pg_kloop<NT, true>(a, m0, c0, As, Bs, w, fr, fq, acc);
+    f32x4 acc[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- epilogue: C layout of a 16x16 tile: col = lane&15, row = 4*(lane>>4) + reg -----------------
-    float bv[NT];
+    const int nkb = a.K >> 4;
+    PgBlock ring[PG_DEPTH];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = c0 + nt * 16 + fr;
-        bv[nt] = (a.bias && col < a.N) ? a.bias[col] : 0.f;
-    }
+    for (int u = 0; u < PG_DEPTH; ++u) pg_load(ring[u], ra, rb, aoff, boff, ldw_bytes, 16 * u, u < nkb);
+    for (int j0 = 0; j0 < nkb; j0 += PG_DEPTH) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rbase = m0 + 32 * w + 16 * i + 4 * fq;          // rows rbase .. rbase+3 (multiple of 4)
-        float zv[NT][4];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = c0 + nt * 16 + fr;
-            float g4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!a.greedy) {
-                if (a.U) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int row = rbase + e;
-                        const float u = (row < a.M && col < a.N) ? a.U[(long long)row * a.ldu + col] : 0.5f;
-                        g4[e] = -logf(-logf(u + 1e-20f) + 1e-20f);
-                    }
-                } else {
-                    // one Philox4x32-10 call = the 4 rows (rbase..rbase+3) of this column
-                    unsigned o[4];
-                    philox4x32((unsigned)col, (unsigned)(rbase >> 2), a.step, 0u, (unsigned)a.seed, (unsigned)(a.seed >> 32), o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float u = (float)(o[e] >> 8) * (1.0f / 16777216.0f);
-                        g4[e] = -__logf(-__logf(u + 1e-20f) + 1e-20f);
-                    }
-                }
+        for (int u = 0; u < PG_DEPTH; ++u) {
+            if (j0 + u < nkb) {                              // wave-uniform
+                pg_mma(ring[u], acc);
+                pg_load(ring[u], ra, rb, aoff, boff, ldw_bytes, 16 * (j0 + u + PG_DEPTH), j0 + u + PG_DEPTH < nkb);
             }
+        }
+    }
+
+    // ---- epilogue: C layout of a 16x16 tile: col = lane&15, row = 4*(lane>>4) + reg; tile c = columns c0+5*fr+c
+    const int rbase = m0 + 4 * fq;                            // rows rbase .. rbase+3 (multiple of 4)
+    float zv[5][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = rbase + e;
-                const float x = acc[i][nt][e] + bv[nt];
-                float zz = a.greedy ? x : (x * a.scale + g4[e]);
-                const bool valid = (row < a.M) && (col < a.N);
-                if (valid && a.z) a.z[(long long)row * a.ldz + col] = zz;
-                zv[nt][e] = valid ? zz : -INFINITY;
+    for (int c = 0; c < 5; ++c) {
+        const int col = c0 + 5 * fr + c;
+        const bool cvalid = col < a.N;
+        const float bv = (a.bias && cvalid) ? a.bias[col] : 0.f;
+        float g4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!a.greedy) {
+            if (a.U) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = rbase + e;
+                    const float u = (row < a.M && cvalid) ? a.U[(long long)row * a.ldu + col] : 0.5f;
+                    g4[e] = -logf(-logf(u + 1e-20f) + 1e-20f);
+                }
+            } else {
+                // one Philox4x32-10 call = the 4 rows (rbase..rbase+3) of this column
+                unsigned o[4];
+                philox4x32((unsigned)col, (unsigned)(rbase >> 2), a.step, 0u, (unsigned)a.seed, (unsigned)(a.seed >> 32), o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = (float)(o[e] >> 8) * (1.0f / 16777216.0f);
+                    g4[e] = -__logf(-__logf(u + 1e-20f) + 1e-20f);
+                }
             }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float m = -INFINITY; int mi = 0x7fffffff;
+            const float xx = acc[c][e] + bv;
+            const float zz = a.greedy ? xx : (xx * a.scale + g4[e]);
+            const bool valid = cvalid && (rbase + e < a.M);
+            zv[c][e] = valid ? zz : -INFINITY;
+        }
+    }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float v = zv[nt][e];
-                if (v > m) { m = v; mi = c0 + nt * 16 + fr; }
-            }
-            // reduce over the 16 lanes that share this row (lanes differ in fr only)
+    for (int e = 0; e < 4; ++e) {
+        const int row = rbase + e;
+        if (a.z && row < a.M) {
+            float* pz = a.z + (long long)row * a.ldz + c0 + 5 * fr;
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                const float om = __shfl_xor(m, o);
-                const int oi = __shfl_xor(mi, o);
-                if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
-            }
-            float s = 0.f;
-            if (!a.greedy) {
+            for (int c = 0; c < 5; ++c)
+                if (c0 + 5 * fr + c < a.N) pz[c] = zv[c][e];
+        }
+        float m = -INFINITY; int mi = 0x7fffffff;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) s += (zv[nt][e] == -INFINITY) ? 0.f : expf((zv[nt][e] - m) * a.inv_tau);
+        for (int c = 0; c < 5; ++c)
+            if (zv[c][e] > m) { m = zv[c][e]; mi = c0 + 5 * fr + c; }
+        // reduce over the 16 lanes that share this row (lanes differ in fr only)
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            }
-            const int row = rbase + e;
-            if (fr == 0 && row < a.M) {
-                float* p = a.part + ((long long)row * a.nstrips + strip) * 4;
-                p[0] = m; p[1] = s; p[2] = __int_as_float(mi); p[3] = 0.f;
-            }
+        for (int o = 8; o > 0; o >>= 1) {
+            const float om = __shfl_xor(m, o);
+            const int oi = __shfl_xor(mi, o);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+        float s = 0.f;
+        if (!a.greedy) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) s += (zv[c][e] == -INFINITY) ? 0.f : expf((zv[c][e] - m) * a.inv_tau);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        }
+        if (fr == 0 && row < a.M) {
+            float* p = a.part + ((long long)row * a.nstrips + strip) * 4;
+            p[0] = m; p[1] = s; p[2] = __int_as_float(mi); p[3] = 0.f;
         }
     }
 }
@@ -236,16 +236,9 @@ __global__ __launch_bounds__(64) void proj_gumbel_final_kernel(PgFinalArgs a) {
     }
 }
 
-static int pg_nt(int N) {
-    for (int nt = 1; nt <= 4; ++nt)
-        if ((long long)16 * nt * 256 >= N) return nt;
-    return 4;
-}
-
 extern "C" long long a4nt_proj_gumbel_part_floats(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
-    const int sw = 16 * pg_nt(N);
-    return (long long)M * ((N + sw - 1) / sw) * 4;
+    return (long long)M * ((N + PG_BC - 1) / PG_BC) * 4;
 }
 
 extern "C" int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh, const float* W, int ldw,
@@ -254,21 +247,20 @@ extern "C" int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh
                                     float* stats, long long* tok, float* val_in, float* val_out, int* gen_lens,
                                     unsigned char* done, long long end_c, void* stream) {
     if (M <= 0) return A4NT_OK;
-    if (N <= 0 || K <= 0 || !h || !W || !part || !tok || (!greedy && tau <= 0.f)) {
-        a4nt_set_error("a4nt_proj_gumbel_fwd: bad arguments (N=%d K=%d tau=%g)", N, K, (double)tau);
+    if (N <= 0 || K <= 0 || (K & 15) || !h || !W || !part || !tok || (!greedy && tau <= 0.f) ||
+        (reinterpret_cast<uintptr_t>(h) & 15) || (ldh & 3)) {
+        a4nt_set_error("a4nt_proj_gumbel_fwd: bad arguments (N=%d, K=%d must be a multiple of 16, tau=%g, h 16-byte "
+                       "aligned with ldh a multiple of 4)", N, K, (double)tau);
         return A4NT_ERR_ARG;
     }
-    const int nt = pg_nt(N), sw = 16 * nt;
     ProjGumbelArgs a;
     a.h = h; a.ldh = ldh; a.W = W; a.ldw = ldw; a.bias = bias; a.M = M; a.N = N; a.K = K;
     a.scale = scale; a.inv_tau = greedy ? 1.f : 1.f / tau; a.greedy = greedy; a.U = U; a.ldu = ldu; a.seed = seed;
-    a.step = step; a.z = z; a.ldz = ldz; a.part = part; a.nstrips = (N + sw - 1) / sw;
-    dim3 grid(a.nstrips, (M + PG_BM - 1) / PG_BM), block(256);
+    a.step = step; a.z = z; a.ldz = ldz; a.part = part; a.nstrips = (N + PG_BC - 1) / PG_BC;
+    const int nrb = (M + PG_BM - 1) / PG_BM;
+    dim3 grid(((a.nstrips + 7) / 8) * 8 * nrb), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (nt == 1) hipLaunchKernelGGL(proj_gumbel_kernel<1>, grid, block, 0, s, a);
-    else if (nt == 2) hipLaunchKernelGGL(proj_gumbel_kernel<2>, grid, block, 0, s, a);
-    else if (nt == 3) hipLaunchKernelGGL(proj_gumbel_kernel<3>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(proj_gumbel_kernel<4>, grid, block, 0, s, a);
+    hipLaunchKernelGGL(proj_gumbel_kernel, grid, block, 0, s, a);
     int rc = a4nt_check_launch("proj_gumbel");
     if (rc != A4NT_OK) return rc;
     PgFinalArgs f;

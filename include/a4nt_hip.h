@@ -109,8 +109,9 @@ int a4nt_gumbel_bwd(int B, int V, float* ds, int ldd, const float* y, int ldy, c
 
 /* Fused output projection + Gumbel-softmax sampling of one free-running decoder step:
  * z = scale*(h W + b) + gumbel(u) (greedy: z = h W + b), per-row arg max / softmax(z/tau) statistics,
- * straight-through value, done / gen_lens bookkeeping.  All M <= rows x a 16*NT-column vocabulary strip
- * per workgroup (v_mfma_f32_16x16x4_f32), strips merged by a finalize kernel.  z [M][ldz] is saved for
+ * straight-through value, done / gen_lens bookkeeping.  One wave per 16-row x 80-column output tile
+ * (v_mfma_f32_16x16x4_f32 fed from registers, no LDS), strips merged by a finalize kernel.  K must be a
+ * multiple of 16, h 16-byte aligned with ldh a multiple of 4.  z [M][ldz] is saved for
  * a4nt_gumbel_bwd(inv_tau = 1/tau) (may be NULL); part is scratch of a4nt_proj_gumbel_part_floats().
  * Replaces: dec_out = p_rnn.mm(W)+b; gumbel_softmax_sample(dec_out*scale, tau); argmax; done/len
  * updates (char_translator.py:377-392) -- softmax((log_softmax(x)+g)/tau) == softmax((x+g)/tau). */

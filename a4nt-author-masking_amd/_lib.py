@@ -18,6 +18,8 @@ _SIGS = {
     'a4nt_sgemm': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int,
                            c_longlong, P]),
     'a4nt_sgemm_tile': (c_int, [c_int, c_int, c_int]),
+    'a4nt_sgemm_skinny_ksplit': (c_int, [c_int, c_int, c_int]),
+    'a4nt_sgemm_skinny': (c_int, [c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_longlong, P]),
     'a4nt_lstm_geometry': (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     'a4nt_lstm_set_max_workgroups': (c_int, [c_int]),
     'a4nt_lstm_xch_floats': (c_longlong, [c_int, c_int, c_int]),

@@ -92,12 +92,49 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, beta=0, ksplit=1
         if not beta:
             out.zero_()
         return out
+    if not transA and not transB and ksplit == 1 and M <= 256 and N >= 2048 and K >= 64:
+        # few rows x wide [K,N] weight (one decoder step's projection): the LDS-free per-wave kernel is faster
+        label = 'skinny_nn' if TIMER is not None else None
+        with _Timed(label, 2.0 * M * N * K):
+            check(lib.a4nt_sgemm_skinny(0, M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc, _p(bias), int(beta), 1, 0,
+                                        _s()), 'a4nt_sgemm_skinny')
+        return out
     label = None
     if TIMER is not None:
         label = 'sgemm_%s_%d' % ('tn' if transA else ('nt' if transB else 'nn'), lib.a4nt_sgemm_tile(M, N, int(ksplit)))
     with _Timed(label, 2.0 * M * N * K):
         check(lib.a4nt_sgemm(int(transA), int(transB), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc,
                              _p(bias), int(beta), int(ksplit), M * ldc if ksplit > 1 else 0, _s()), 'a4nt_sgemm')
+    return out
+
+
+def skinny_ksplit(M, N, K):
+    return int(_lib.load().a4nt_sgemm_skinny_ksplit(int(M), int(N), int(K)))
+
+
+def gemm_skinny(A, B, transB=False, bias=None, out=None, beta=0, ksplit=1):
+    """out (+)= A @ op(B) (+ bias) through a4nt_sgemm_skinny (few rows: one decoder step's batch).
+    ksplit > 1: `out` must be [ksplit, M, N] slabs (or None: allocated)."""
+    lib = _lib.load()
+    A = _rowmajor(_f32(A, 'gemm_skinny A'))
+    B = _rowmajor(_f32(B, 'gemm_skinny B'))
+    M, K = A.shape
+    N, Kb = (B.shape[0], B.shape[1]) if transB else (B.shape[1], B.shape[0])
+    if K != Kb:
+        raise A4NTError('gemm_skinny: inner dimensions differ (%d vs %d)' % (K, Kb))
+    if out is None:
+        out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), device=A.device, dtype=torch.float32)
+        beta = 0
+    if ksplit > 1:
+        assert out.dim() == 3 and out.shape[0] == ksplit and out.is_contiguous() and not beta
+        ldc, slab = N, M * N
+    else:
+        assert out.dim() == 2 and out.stride(1) == 1
+        ldc, slab = out.stride(0), 0
+    label = ('skinny_nt' if transB else 'skinny_nn') if TIMER is not None else None
+    with _Timed(label, 2.0 * M * N * K):
+        check(lib.a4nt_sgemm_skinny(int(transB), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc, _p(bias), int(beta),
+                                    int(ksplit), slab, _s()), 'a4nt_sgemm_skinny')
     return out
 
 

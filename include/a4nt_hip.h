@@ -41,6 +41,16 @@ int a4nt_sgemm(int transA, int transB, int M, int N, int K, const float* A, int 
  * profiling.  Nothing in the reference corresponds (torch picks its BLAS kernel internally). */
 int a4nt_sgemm_tile(int M, int N, int ksplit);
 
+/* C[M,N] (+)= A[M,K] * op(B) (+ bias) for few rows (M = the batch of ONE decoder step): no LDS, one wave
+ * per 16-row x 64/80-column tile and K slab, v_mfma_f32_16x16x4_f32 fed from a register ring.
+ * transB=0: B is [K][N]; transB=1: B is stored [N][K].  ksplit>1 writes slabs at C + z*slab_stride
+ * (beta must be 0); a4nt_sgemm_skinny_ksplit suggests the split that fills the chip's 1024 SIMDs.
+ * Replaces, per generated token: emb = samp.mm(char_emb.weight) backward (char_translator.py:381),
+ * dec_out = p_rnn.mm(W) backward (:377) and the decoder nn.LSTM step's backward (:398). */
+int a4nt_sgemm_skinny_ksplit(int M, int N, int K);
+int a4nt_sgemm_skinny(int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                      int ldc, const float* bias, int beta, int ksplit, long long slab_stride, void* stream);
+
 /* Geometry of the persistent LSTM sweeps for a batch of B rows and hidden size H
  * (H in {64, 128, 256, 512, 1024}): rows per group = 16*mt, groups*(H/16) workgroups <= 256. */
 int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out);

@@ -47,6 +47,34 @@ def test_sgemm(ops, M, N, K, tA, tB):
     assert torch.equal(big[0], _rand(M + 3, N + 5, seed=4)[0].cuda()), 'sgemm wrote outside its output'
 
 
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (5, 7, 3), (16, 64, 16), (37, 301, 100), (128, 10001, 512), (128, 512, 10001),
+                                   (128, 1024, 2048), (200, 81, 130)])
+@pytest.mark.parametrize('tB', [0, 1])
+def test_sgemm_skinny(ops, M, N, K, tB):
+    A = _rand(M, K, seed=41)
+    B = _rand(N, K, seed=42) if tB else _rand(K, N, seed=42)
+    bias = _rand(N, seed=43)
+    ref = A.double() @ (B.t() if tB else B).double()
+    out = ops.gemm_skinny(A.cuda(), B.cuda(), bool(tB), bias=bias.cuda())
+    tol = 2e-6 * max(1.0, (K / 1000.0) ** 0.5)      # one fp32 accumulation chain over K terms
+    assert_close(out, (ref + bias.double()).float(), tol, 'skinny')
+    # accumulate into a strided, unaligned view; nothing outside it is touched
+    big = _rand(M + 3, N + 5, seed=44).cuda()
+    view = big[1:M + 1, 3:N + 3]
+    before = view.clone()
+    ops.gemm_skinny(A.cuda(), B.cuda(), bool(tB), out=view, beta=1)
+    assert_close(view, (before.cpu().double() + ref).float(), tol, 'skinny beta=1 strided')
+    ref_big = _rand(M + 3, N + 5, seed=44)
+    assert torch.equal(big[0].cpu(), ref_big[0]) and torch.equal(big[:, :3].cpu(), ref_big[:, :3])
+    # split-K slabs at the suggested factor
+    ks = ops.skinny_ksplit(M, N, K)
+    assert ks >= 1
+    if ks > 1:
+        slabs = ops.gemm_skinny(A.cuda(), B.cuda(), bool(tB), ksplit=ks)
+        assert slabs.shape == (ks, M, N)
+        assert_close(ops.slab_reduce(slabs), ref.float(), 2e-6, 'skinny split-K')
+
+
 def test_sgemm_splitk(ops):
     A, B = _rand(128, 10001, seed=5), _rand(512, 10001, seed=6)
     ref = A.double() @ B.double().t()

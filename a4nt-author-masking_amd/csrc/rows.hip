@@ -172,26 +172,35 @@ extern "C" int a4nt_gumbel_fwd(int B, int V, const float* logits, int ldl, const
     return a4nt_check_launch("gumbel_fwd");
 }
 
-// ds (in) -> dlogits (out, in place).  p = exp((y - stats[0]) * inv_tau) / stats[1]
+// ds (in) -> dlogits (out; may be ds itself).  p = exp((y - stats[0]) * inv_tau) / stats[1]
 // (inv_tau = 1 when y already holds the tempered log-probs; 1/tau when it holds z = scale*x + g).
-__global__ __launch_bounds__(1024) void gumbel_bwd_kernel(int V, float* ds, int ldd, const float* y, int ldy,
-                                                         const float* stats, float coef, float inv_tau) {
+// One row is only 40 KB, and 128 rows on 128 workgroups leave half the chip idle with every workgroup
+// latency-bound; when out is a separate buffer, gridDim.y workgroups share a row: each computes the whole
+// row's <p, ds> (the re-reads hit L2) and writes its own slice of the output.
+__global__ __launch_bounds__(1024) void gumbel_bwd_kernel(int V, const float* ds, int ldd, const float* y, int ldy,
+                                                         const float* stats, float coef, float inv_tau, float* out, int ldo) {
     __shared__ float red[ROWS_MAXW];
     const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
-    float* d = ds + (long long)b * ldd;
+    const float* d = ds + (long long)b * ldd;
     const float* yy = y + (long long)b * ldy;
+    float* o = out + (long long)b * ldo;
     const float m2 = stats[2 * b], inv = 1.0f / stats[2 * b + 1];
     float dot = 0.f;
     for (int v = tid; v < V; v += NT) dot += (expf((yy[v] - m2) * inv_tau) * inv) * d[v];
     dot = block_sum(dot, red);
-    for (int v = tid; v < V; v += NT) d[v] = coef * (expf((yy[v] - m2) * inv_tau) * inv) * (d[v] - dot);
+    const int per = (V + gridDim.y - 1) / gridDim.y;
+    const int v0 = blockIdx.y * per, v1 = min(V, v0 + per);
+    for (int v = v0 + tid; v < v1; v += NT) o[v] = coef * (expf((yy[v] - m2) * inv_tau) * inv) * (d[v] - dot);
 }
 
-extern "C" int a4nt_gumbel_bwd(int B, int V, float* ds, int ldd, const float* y, int ldy, const float* stats,
-                               float coef, float inv_tau, void* stream) {
+extern "C" int a4nt_gumbel_bwd(int B, int V, const float* ds, int ldd, const float* y, int ldy, const float* stats,
+                               float coef, float inv_tau, float* out, int ldo, void* stream) {
     if (B <= 0) return A4NT_OK;
-    if (V <= 0 || !ds || !y || !stats) { a4nt_set_error("a4nt_gumbel_bwd: bad arguments"); return A4NT_ERR_ARG; }
-    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(B), dim3(V >= 4096 ? 1024 : 256), 0, (hipStream_t)stream, V, ds, ldd, y, ldy, stats, coef, inv_tau);
+    if (V <= 0 || !ds || !y || !stats || !out) { a4nt_set_error("a4nt_gumbel_bwd: bad arguments"); return A4NT_ERR_ARG; }
+    // in place: one workgroup per row (another workgroup of the row would still be reading what this one overwrites)
+    const int q = (out != ds && V >= 4096 && B * 4 <= 2048) ? 4 : 1;
+    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(B, q), dim3(V >= 4096 ? 1024 : 256), 0, (hipStream_t)stream, V, ds, ldd, y, ldy,
+                       stats, coef, inv_tau, out, ldo);
     return a4nt_check_launch("gumbel_bwd");
 }
 

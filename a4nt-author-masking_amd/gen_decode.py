@@ -241,20 +241,23 @@ class _GenDecode(Function):
         w_ic = w_ih[:, :Hc]
         w_ie = w_ih[:, Hc:].contiguous()
         Wcat = torch.cat([w_hh, w_ie], dim=1).contiguous()             # [4H, H+E]
+        # dlogits of every step (separate from S so that several workgroups can share a row in the Gumbel backward)
+        D2 = ops.padded_rows(n * B, V, dev)
+        D = D2.unflatten(0, (n, B))
         coef = float(cfg['scale']) / float(cfg['tau'])
         dc = torch.zeros((B, H), device=dev)
         dG = torch.empty((n, B, 4 * H), device=dev)
         # rec[t] = dgates_t * [W_hh | W_ie]: columns [0,H) = dh flowing into step t-1, [H,H+E) = d(emb input of step t)
         rec = torch.empty((n, B, H + E), device=dev)
-        ks_v = max(1, ops._auto_ksplit(B, H, V))
+        ks_v = max(1, min(16, ops._auto_ksplit(B, H, V)))
         ks_r = max(1, ops._auto_ksplit(B, H + E, 4 * H))
         dh_slabs = torch.empty((ks_v, B, H), device=dev)
         rec_slabs = torch.empty((ks_r, B, H + E), device=dev) if ks_r > 1 else None
         for t in range(n - 1, -1, -1):
             if t < n - 1:
                 gemm(rec[t + 1][:, H:], emb_W, transB=True, out=S[t], beta=1)      # += d(emb_{t+1}) * E^T
-            ops.gumbel_bwd_rows(S[t], ybuf[t], stats[t], coef, 1.0 / float(cfg['tau']))   # S[t] := dlogits_t
-            gemm(S[t], W_out, transB=True, out=dh_slabs if ks_v > 1 else dh_slabs[0], ksplit=ks_v)
+            ops.gumbel_bwd_rows(S[t], ybuf[t], stats[t], coef, 1.0 / float(cfg['tau']), out=D[t])   # dlogits_t
+            gemm(D[t], W_out, transB=True, out=dh_slabs if ks_v > 1 else dh_slabs[0], ksplit=ks_v)
             _lib.check(lib.a4nt_lstm_cell_bwd(B, H, ops._p(gates[t]), ops._p(cs[t]), ops._p(cs[t - 1] if t > 0 else None),
                                               ops._p(dh_slabs), ks_v, B * H,
                                               ops._p(rec[t + 1]) if t < n - 1 else None, H + E,
@@ -268,8 +271,8 @@ class _GenDecode(Function):
                 gemm(dG[t], Wcat, out=rec[t])
         demb_all = rec[:, :, H:].contiguous()
         dG2 = dG.view(n * B, 4 * H)
-        d_W_out = gemm_auto(hs_all[1:n + 1].reshape(n * B, H), S2, transA=True)
-        d_b_out = colsum(S2)
+        d_W_out = gemm_auto(hs_all[1:n + 1].reshape(n * B, H), D2, transA=True)
+        d_b_out = colsum(D2)
         d_w_hh = gemm_auto(dG2, hs_all[:n].reshape(n * B, H), transA=True)
         # decoder inputs: step 0 = E[x0] (nn.Embedding, padding row 0 has no gradient);
         # step t>0 = val_in[t-1]*E[tok[t-1]] (a dense mm in the reference: no padding semantics, and its

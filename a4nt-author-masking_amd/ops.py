@@ -464,11 +464,14 @@ def gumbel_rows(logits, U, seed, step, scale, tau, hard, greedy, y, stats, tok, 
                               V if dense is not None else 0, _s()), 'a4nt_gumbel_fwd')
 
 
-def gumbel_bwd_rows(ds, y, stats, coef, inv_tau=1.0):
+def gumbel_bwd_rows(ds, y, stats, coef, inv_tau=1.0, out=None):
+    """out (default: ds, in place) = coef * p * (ds - <p, ds>) per row."""
     lib = _lib.load()
     B, V = ds.shape
-    check(lib.a4nt_gumbel_bwd(B, V, _p(ds), _ld(ds), _p(y), _ld(y), _p(stats), float(coef), float(inv_tau), _s()),
-          'a4nt_gumbel_bwd')
+    if out is None:
+        out = ds
+    check(lib.a4nt_gumbel_bwd(B, V, _p(ds), _ld(ds), _p(y), _ld(y), _p(stats), float(coef), float(inv_tau), _p(out),
+                              _ld(out), _s()), 'a4nt_gumbel_bwd')
 
 
 def proj_gumbel(h, W, bias, U, seed, step, scale, tau, hard, greedy, z, part, stats, tok, val_in, val_out, gen_lens,

@@ -112,10 +112,11 @@ int a4nt_gumbel_fwd(int B, int V, const float* logits, int ldl, const float* U, 
                     unsigned step, float scale, float tau, int hard, int greedy, float* y, int ldy, float* stats,
                     long long* tok, float* val_in, float* val_out, int* gen_lens, unsigned char* done,
                     long long end_c, float* dense, int ldd, void* stream);
-/* In place: ds -> dlogits = coef * p * (ds - <p,ds>), p = softmax(y) from the saved y / stats.
+/* out = dlogits = coef * p * (ds - <p,ds>), p = softmax(y) from the saved y / stats.  out may be ds (in
+ * place: one workgroup per row); a separate out lets four workgroups share a row.
  * Replaces: autograd backward of gumbel_softmax_sample (char_translator.py:17-28). */
-int a4nt_gumbel_bwd(int B, int V, float* ds, int ldd, const float* y, int ldy, const float* stats, float coef,
-                    float inv_tau, void* stream);
+int a4nt_gumbel_bwd(int B, int V, const float* ds, int ldd, const float* y, int ldy, const float* stats, float coef,
+                    float inv_tau, float* out, int ldo, void* stream);
 
 /* Fused output projection + Gumbel-softmax sampling of one free-running decoder step:
  * z = scale*(h W + b) + gumbel(u) (greedy: z = h W + b), per-row arg max / softmax(z/tau) statistics,

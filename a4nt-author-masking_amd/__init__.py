@@ -14,8 +14,8 @@ from .char_translator import CharTranslator                               # noqa
 from .char_lstm import CharLstm                                           # noqa: F401
 from .char_cnn import CharCNN                                             # noqa: F401
 from .model_utils import get_classifier                                   # noqa: F401
-from .adv_step import (adv_forward_pass, d_update, g_update, make_optimizers, GradAllReducer,   # noqa: F401
-                       synthetic_batch)
+from .adv_step import (adv_forward_pass, d_update, g_update, fused_update, make_optimizers,    # noqa: F401
+                       GradAllReducer, synthetic_batch)
 from .ops import check_timeouts, lstm_set_max_workgroups                  # noqa: F401
 
 load_library()

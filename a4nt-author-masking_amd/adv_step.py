@@ -19,19 +19,22 @@ from .gen_decode import SoftSamples
 
 def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all', maxlen=100, auths=None,
                      cycle_compute=False, append_symb=None, temp=0.5, cycle_loss_type='ml', targs=None,
-                     real_batch=None, before_disc=None):
+                     real_batch=None, before_disc=None, gen=None):
     """Returns (eval_logits [B,C] in input order, enc_out, samples (SoftSamples, generation order), gen_lens,
     char_outs[, cycle loss][, (real logits, real enc_out)]).
 
     real_batch = (ids, lens): also classify a batch of real sentences; when the classifier offers
     forward_classify_multi the generated and the real batch share one pass (train_adversarial_translator.py
     :448 and :463 are two separate forward_classify calls in the reference; rows are independent)."""
-    if backprop_for in ('eval', 'None'):
-        modelGen.eval()
+    if gen is not None:
+        samples, gen_lens, char_outs = gen          # generated beforehand (fused_update)
     else:
-        modelGen.train()
-    samples, gen_lens, char_outs = modelGen.forward_advers_gen(
-        inps, lens, soft_samples=True, end_c=end_c, n_max=maxlen, temp=temp, auths=1 - auths, compact=True)
+        if backprop_for in ('eval', 'None'):
+            modelGen.eval()
+        else:
+            modelGen.train()
+        samples, gen_lens, char_outs = modelGen.forward_advers_gen(
+            inps, lens, soft_samples=True, end_c=end_c, n_max=maxlen, temp=temp, auths=1 - auths, compact=True)
     if before_disc is not None:
         before_disc()                   # e.g. the deferred discriminator step: the generation above did not need it
     gl_host = gen_lens.cpu()
@@ -226,7 +229,7 @@ class GradAllReducer(object):
 
 
 def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c, maxlen, temp, step=True,
-             reducer=None, defer=False):
+             reducer=None, defer=False, gen=None):
     """One discriminator update (:433-547): BCE(real, 1) + BCE(fake, 0) on column 1 - c_aid, RMSprop, no clipping.
 
     defer=True: return with the gradient exchange in flight and the optimizer step not yet applied;
@@ -234,11 +237,12 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
     generator update first touches the discriminator, so the exchange and the step's host work overlap
     the generator's free-running generation (which does not read the discriminator)."""
     _set_requires_grad(modelEval, True)
-    _set_requires_grad(modelGen, False)
+    if gen is None:
+        _set_requires_grad(modelGen, False)
     inps, targs, auths, lens = src_batch
     _, gt_targs, _, gt_lens = tgt_batch
     outs = adv_forward_pass(modelGen, modelEval, inps, lens, end_c=end_c, backprop_for='eval', maxlen=maxlen,
-                            auths=auths, temp=temp, real_batch=(gt_targs, gt_lens))
+                            auths=auths, temp=temp, real_batch=(gt_targs, gt_lens), gen=gen)
     eval_out_gt = outs[-1]
     optimEval.zero_grad()
     targ_aid = 1 - c_aid
@@ -268,18 +272,19 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
 
 
 def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, append_symb, cycle_loss_type='ml',
-             cycle_loss_w=1.0, grad_clip=10.0, step=True, reducer=None, before_disc=None):
+             cycle_loss_w=1.0, grad_clip=10.0, step=True, reducer=None, before_disc=None, gen=None):
     """One generator update (:553-735): 5*BCE(fake, 1) + w * CE reconstruction, clip_grad_norm, RMSprop.
     before_disc: callable run after the generation forward and before the discriminator is used
     (the deferred tail of d_update)."""
     _set_requires_grad(modelEval, False)
-    _set_requires_grad(modelGen, True)
-    optimGen.zero_grad()
+    if gen is None:
+        _set_requires_grad(modelGen, True)
+        optimGen.zero_grad()
     modelGen.train()
     inps, targs, auths, lens = batch
     outs = adv_forward_pass(modelGen, modelEval, inps, lens, end_c=end_c, maxlen=maxlen, auths=auths,
                             cycle_compute=(cycle_loss_type is not None), append_symb=append_symb, temp=temp,
-                            cycle_loss_type=cycle_loss_type, targs=targs, before_disc=before_disc)
+                            cycle_loss_type=cycle_loss_type, targs=targs, before_disc=before_disc, gen=gen)
     if cycle_loss_type == 'ml':
         w_tok = reducer.token_weight(sum(int(l) for l in lens)) if reducer is not None else 1.0
         cyc_loss = cycle_loss_w * w_tok * outs[-1]
@@ -302,6 +307,39 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
     return {'loss': loss_tot.detach(), 'loss_gan': loss_gan.detach(), 'cyc_loss': cyc_loss.detach(),
             'grad_norm': gnorm.detach(), 'err': err, 'gen_lens': outs[3], 'char_outs': outs[4],
             'fake_logits': outs[0].detach()}
+
+
+def fused_update(modelGen, modelEval, optimGen, optimEval, src_batch, tgt_batch, gen_batch, c_aid, end_c, maxlen, temp,
+                 append_symb, cycle_loss_type='ml', cycle_loss_w=1.0, grad_clip=10.0, step=True, reducers=(None, None)):
+    """d_update(src_batch, tgt_batch) followed by g_update(gen_batch), with ONE free-running generation for the
+    2B source sentences of both updates.
+
+    The generator's weights are the same in both generations of the reference's loop (the discriminator
+    update between them does not touch the generator, train_adversarial_translator.py:433-547) and
+    forward_advers_gen has no dropout, so generating the two batches in one batch of 2B rows is the same
+    computation; per decoding step the kernels then work on 2B rows instead of being launched twice.
+    Only the generator update's rows keep what BPTT needs (grad_rows).  Returns (d result, g result)."""
+    s_inps, _, s_auths, s_lens = src_batch
+    g_inps, _, g_auths, g_lens = gen_batch
+    B = s_inps.shape[1]
+    assert g_inps.shape == s_inps.shape
+    _set_requires_grad(modelGen, True)
+    optimGen.zero_grad()
+    modelGen.train()
+    samples, gen_lens, char_outs = modelGen.forward_advers_gen(
+        torch.cat([s_inps, g_inps], dim=1), list(s_lens) + list(g_lens), soft_samples=True, end_c=end_c, n_max=maxlen,
+        temp=temp, auths=1 - torch.cat([s_auths, g_auths]), compact=True, grad_rows=(B, 2 * B))
+    gl = gen_lens.cpu()
+    n_d, n_g = int(gl[:B].max()), int(gl[B:].max())
+    tok = torch.stack(list(char_outs), 0) if not torch.is_tensor(char_outs) else char_outs
+    gen_d = (samples.rows(0, B, n_d, differentiable=False), gen_lens[:B], list(tok[:n_d, :B].unbind(0)))
+    gen_g = (samples.rows(B, 2 * B, n_g), gen_lens[B:], list(tok[:n_g, B:].unbind(0)))
+    rd = d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c, maxlen, temp, step=step,
+                  reducer=reducers[1], gen=gen_d)
+    rg = g_update(modelGen, modelEval, optimGen, gen_batch, c_aid, end_c, maxlen, temp, append_symb,
+                  cycle_loss_type=cycle_loss_type, cycle_loss_w=cycle_loss_w, grad_clip=grad_clip, step=step,
+                  reducer=reducers[0], gen=gen_g)
+    return rd, rg
 
 
 def synthetic_batch(gen, T, B, V, lens=None, start=2, end=1):

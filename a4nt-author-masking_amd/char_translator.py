@@ -231,12 +231,8 @@ class CharTranslator(nn.Module):
         return enc_hidden[0][-1]
 
     # -- free running generation (char_translator.py:314-401) -----------------------------------
-    def forward_advers_gen(self, x, lengths_inp, h_prev=None, n_max=100, end_c=-1, soft_samples=False, temp=0.1,
-                           auths=None, adv_inp=False, n_samples=1, compact=False):
-        self._need_encoder('forward_advers_gen')
-        dev = self._dev()
-        soft_in = adv_inp or isinstance(x, SoftSamples)
-        B = x.shape[1]
+    def _gen_context(self, x, lengths_inp, h_prev, soft_in, auths):
+        """Encoder pass of forward_advers_gen (char_translator.py:321-345) -> ctxt [B, ctx_size]."""
         emb = self._embed_input(x, soft_in, drop=False)
         enc_out, enc_hidden = self._encode(emb, lengths_inp, h_prev)
         if self.max_pool_rnn:
@@ -244,19 +240,42 @@ class CharTranslator(nn.Module):
         else:
             ctxt = enc_hidden[0][-1]
         if self.pad_auth_vec:
-            ctxt = torch.cat([ctxt, self.auth_emb(auths.to(dev))], dim=-1)
+            ctxt = torch.cat([ctxt, self.auth_emb(auths.to(self._dev()))], dim=-1)
+        return ctxt
+
+    def forward_advers_gen(self, x, lengths_inp, h_prev=None, n_max=100, end_c=-1, soft_samples=False, temp=0.1,
+                           auths=None, adv_inp=False, n_samples=1, compact=False, grad_rows=None):
+        """grad_rows = (r0, r1) (extension, fused path with compact=True only): only batch columns [r0, r1)
+        will be differentiated; the others are encoded without a graph and share the decoding loop."""
+        self._need_encoder('forward_advers_gen')
+        dev = self._dev()
+        soft_in = adv_inp or isinstance(x, SoftSamples)
+        B = x.shape[1]
+        if grad_rows is None:
+            ctxt = self._gen_context(x, lengths_inp, h_prev, soft_in, auths)
+        else:
+            r0, r1 = grad_rows
+            assert compact and not soft_in and h_prev is None and 0 <= r0 < r1 <= B
+            parts = []
+            for a_, b_, grad in ((0, r0, False), (r0, r1, True), (r1, B, False)):
+                if b_ > a_:
+                    with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
+                        parts.append(self._gen_context(x[:, a_:b_], lengths_inp[a_:b_], None, False, auths[a_:b_]))
+            ctxt = torch.cat(parts, dim=0)
         if soft_samples:
             self.temp = temp
         dec = self._decoder(auths)
         fused = (self.dec_num_rec_layers == 1 and not soft_in and n_samples == 1 and not self.learn_gumbel and
                  (self.gumb_type or not soft_samples))
         if not fused:
+            if grad_rows is not None:
+                raise NotImplementedError('grad_rows needs the fused generation path')
             return self._advers_gen_generic(x, soft_in, ctxt, n_max, end_c, soft_samples, temp, n_samples, compact, dec)
         w_ih, w_hh, b_ih, b_hh = rec_layer_params(dec[0], self.en_residual, 0)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         cfg = dict(n_max=n_max, end_c=int(end_c), tau=float(temp), scale=float(self.softmax_scale),
                    hard=bool(self.gumb_type), greedy=not soft_samples, need_grad=need_grad, noise=self._noise,
-                   seed=self.noise_seed, step0=self._noise_step)
+                   seed=self.noise_seed, step0=self._noise_step, grad_rows=grad_rows)
         samples, gen_lens, tok = gen_decode(ctxt, x[0].to(dev), self.char_emb.weight, w_ih, w_hh, b_ih, b_hh,
                                             dec[1], dec[2], cfg)
         self._noise_step += n_max

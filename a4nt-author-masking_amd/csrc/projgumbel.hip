@@ -40,6 +40,7 @@ struct ProjGumbelArgs {
     const float* U; int ldu;
     unsigned long long seed; unsigned step;
     float* z; int ldz;
+    int zrow0, zrows;       // z holds rows [zrow0, zrow0+zrows) only (the rows whose backward will run)
     float* part;            // [M][nstrips][4] = (max z, sum exp((z-max)/tau), arg max as int bits, unused)
     int nstrips;
 };
@@ -162,8 +163,8 @@ __global__ __launch_bounds__(256) void proj_gumbel_kernel(ProjGumbelArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int row = rbase + e;
-        if (a.z && row < a.M) {
-            float* pz = a.z + (long long)row * a.ldz + c0 + 5 * fr;
+        if (a.z && row < a.M && row >= a.zrow0 && row - a.zrow0 < a.zrows) {
+            float* pz = a.z + (long long)(row - a.zrow0) * a.ldz + c0 + 5 * fr;
 #pragma unroll
             for (int c = 0; c < 5; ++c)
                 if (c0 + 5 * fr + c < a.N) pz[c] = zv[c][e];
@@ -243,7 +244,8 @@ extern "C" long long a4nt_proj_gumbel_part_floats(int M, int N) {
 
 extern "C" int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh, const float* W, int ldw,
                                     const float* bias, float scale, float tau, int hard, int greedy, const float* U,
-                                    int ldu, unsigned long long seed, unsigned step, float* z, int ldz, float* part,
+                                    int ldu, unsigned long long seed, unsigned step, float* z, int ldz, int zrow0,
+                                    int zrows, float* part,
                                     float* stats, long long* tok, float* val_in, float* val_out, int* gen_lens,
                                     unsigned char* done, long long end_c, void* stream) {
     if (M <= 0) return A4NT_OK;
@@ -256,7 +258,7 @@ extern "C" int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh
     ProjGumbelArgs a;
     a.h = h; a.ldh = ldh; a.W = W; a.ldw = ldw; a.bias = bias; a.M = M; a.N = N; a.K = K;
     a.scale = scale; a.inv_tau = greedy ? 1.f : 1.f / tau; a.greedy = greedy; a.U = U; a.ldu = ldu; a.seed = seed;
-    a.step = step; a.z = z; a.ldz = ldz; a.part = part; a.nstrips = (N + PG_BC - 1) / PG_BC;
+    a.step = step; a.z = z; a.ldz = ldz; a.zrow0 = zrow0; a.zrows = zrows; a.part = part; a.nstrips = (N + PG_BC - 1) / PG_BC;
     const int nrb = (M + PG_BM - 1) / PG_BM;
     dim3 grid(((a.nstrips + 7) / 8) * 8 * nrb), block(256);
     hipStream_t s = (hipStream_t)stream;

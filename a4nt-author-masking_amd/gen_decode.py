@@ -73,6 +73,14 @@ class SoftSamples(object):
             origin = (h, off + 1, perm)
         return SoftSamples(torch.cat([t0, self.tok]), torch.cat([v0, self.val]), self.vocab, origin)
 
+    def rows(self, r0, r1, n=None, differentiable=True):
+        """Batch columns [r0, r1) and the first n steps.  With differentiable=True the result keeps this
+        object's origin, whose frame must be exactly those columns (forward_advers_gen(grad_rows=(r0, r1)))."""
+        n = self.tok.shape[0] if n is None else n
+        val = self.val[:n, r0:r1] if differentiable else self.val[:n, r0:r1].detach()
+        return SoftSamples(self.tok[:n, r0:r1].contiguous(), val.contiguous(), self.vocab,
+                           self.origin if differentiable else None)
+
     def to_dense(self):
         return _DenseFromCompact.apply(self.val, self.tok, self.vocab, self.origin)
 
@@ -152,6 +160,10 @@ class _GenDecode(Function):
         n_max = int(cfg['n_max'])
         greedy = bool(cfg['greedy'])
         need_grad = bool(cfg['need_grad']) and not greedy
+        # rows [r0, r1) are the ones whose backward pass will run (default: all); the others are generated
+        # in the same launches but nothing is kept for them (adv_step.fused_update: the discriminator
+        # update's no-grad batch and the generator update's batch share one decoding loop)
+        r0, r1 = cfg.get('grad_rows') or (0, B)
         noise = cfg.get('noise')          # list of [B,V] uniforms or None
         w_ic = w_ih[:, :Hc]
         w_ie = w_ih[:, Hc:].contiguous()
@@ -164,7 +176,7 @@ class _GenDecode(Function):
         gates = torch.empty((n_max, B, 4 * H), device=dev)
         cs = torch.empty((n_max, B, H), device=dev)
         # z = scale*logits + gumbel, saved per step for the backward pass only
-        ybuf = torch.empty((n_max, B, V), device=dev) if need_grad else None
+        ybuf = torch.empty((n_max, r1 - r0, V), device=dev) if need_grad else None
         stats = torch.empty((n_max, B, 2), device=dev)
         tok = torch.zeros((n_max, B), dtype=torch.int64, device=dev)
         val_in = torch.ones((n_max, B), device=dev)
@@ -189,7 +201,7 @@ class _GenDecode(Function):
                 assert tuple(U.shape) == (B, V)
             ops.proj_gumbel(hs_all[t + 1], W_out, b_out, U, cfg.get('seed', 0), cfg.get('step0', 0) + t, cfg['scale'],
                             cfg['tau'], cfg['hard'], greedy, ybuf[t] if need_grad else None, part,
-                            stats[t], tok[t], val_in[t], val_out[t], gen_lens, done, cfg['end_c'])
+                            stats[t], tok[t], val_in[t], val_out[t], gen_lens, done, cfg['end_c'], zrow0=r0)
             ran = t + 1
             if cfg['end_c'] >= 0 and (ran % CHECK_EVERY == 0) and ran < n_max and bool(done.all()):
                 break
@@ -203,10 +215,19 @@ class _GenDecode(Function):
         holder['n_out'] = n_out
         ctx.handle = holder['handle']
         ctx.cfg = dict(cfg, noise=None)
-        ctx.n = n_out
+        ctx.rows = (r0, r1, B)
         if need_grad:
-            ctx.save_for_backward(ctxt, tok0, emb_W, w_ih, w_hh_c, W_out, hs_all, gates, cs, ybuf, stats, tok, val_in,
-                                  val_out)
+            if (r0, r1) == (0, B):
+                ctx.n = n_out
+                ctx.save_for_backward(ctxt, tok0, emb_W, w_ih, w_hh_c, W_out, hs_all, gates, cs, ybuf, stats, tok, val_in,
+                                      val_out)
+            else:
+                # keep only the rows that will be differentiated, as dense [.., r1-r0, ..] tensors
+                ctx.n = n_g = max(1, min(int(gen_lens[r0:r1].max().item()), ran))
+                sl = lambda t_: t_[:, r0:r1].contiguous()
+                ctx.save_for_backward(ctxt[r0:r1].contiguous(), tok0[r0:r1].contiguous(), emb_W, w_ih, w_hh_c, W_out,
+                                      sl(hs_all[:n_g + 1]), sl(gates[:n_g]), sl(cs[:n_g]), ybuf, sl(stats[:n_g]),
+                                      sl(tok[:n_g]), sl(val_in[:n_g]), sl(val_out[:n_g]))
         tok_ret = tok[:n_out].clone()
         ctx.mark_non_differentiable(tok_ret, gen_lens)
         return val_out[:n_out].clone(), tok_ret, gen_lens
@@ -217,6 +238,7 @@ class _GenDecode(Function):
         lib = _lib.load()
         (ctxt, tok0, emb_W, w_ih, w_hh, W_out, hs_all, gates, cs, ybuf, stats, tok, val_in, val_out) = ctx.saved_tensors
         cfg, n, handle = ctx.cfg, ctx.n, ctx.handle
+        r0, r1, B_all = ctx.rows
         dev = ctxt.device
         B, Hc = ctxt.shape
         H = w_hh.shape[1]
@@ -290,6 +312,10 @@ class _GenDecode(Function):
         embed_bwd(tok0, demb_all[0], d_emb, None, 0)
         if n > 1:
             embed_bwd(tok[:n - 1], demb_all[1:], d_emb, val_out[:n - 1].contiguous(), -1)
+        if B != B_all:
+            full = torch.zeros((B_all, Hc), device=dev)
+            full[r0:r1] = d_ctxt
+            d_ctxt = full
         return d_ctxt, None, d_emb, d_w_ih, d_w_hh, d_b, d_b, d_W_out, d_b_out, None, None
 
 

@@ -475,15 +475,17 @@ def gumbel_bwd_rows(ds, y, stats, coef, inv_tau=1.0, out=None):
 
 
 def proj_gumbel(h, W, bias, U, seed, step, scale, tau, hard, greedy, z, part, stats, tok, val_in, val_out, gen_lens,
-                done, end_c):
-    """Fused decoder-step projection + Gumbel-softmax sampling (a4nt_proj_gumbel_fwd)."""
+                done, end_c, zrow0=0):
+    """Fused decoder-step projection + Gumbel-softmax sampling (a4nt_proj_gumbel_fwd).
+    z (optional) receives rows [zrow0, zrow0 + z.shape[0]) of the batch."""
     lib = _lib.load()
     M, K = h.shape
     N = W.shape[1]
     with _Timed('proj_gumbel', 2.0 * M * N * K):
         check(lib.a4nt_proj_gumbel_fwd(M, N, K, _p(h), _ld(h), _p(W), _ld(W), _p(bias), float(scale), float(tau),
                                        int(hard), int(greedy), _p(U), _ld(U) if U is not None else 0, int(seed),
-                                       int(step), _p(z), _ld(z) if z is not None else 0, _p(part), _p(stats), _p(tok),
+                                       int(step), _p(z), _ld(z) if z is not None else 0, int(zrow0),
+                                       int(z.shape[0]) if z is not None else 0, _p(part), _p(stats), _p(tok),
                                        _p(val_in), _p(val_out), _p(gen_lens), _p(done), int(end_c), _s()),
               'a4nt_proj_gumbel_fwd')
 

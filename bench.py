@@ -107,10 +107,14 @@ def ml_step(impl, G, optG, batches, it, batch):
     return {'loss': loss.detach()}, {'loss': loss.detach()}
 
 
-def adv_step(impl, G, D, optG, optD, batches, it, batch, reducers):
+def adv_step(impl, G, D, optG, optD, batches, it, batch, reducers, fused=True):
     c_aid = it % 2
     mk = lambda b, a: (b[0], b[1], torch.full((batch,), a, dtype=torch.long), b[2])
     src, tgt, gb = batches[(3 * it) % len(batches)], batches[(3 * it + 1) % len(batches)], batches[(3 * it + 2) % len(batches)]
+    if fused:
+        # one free-running generation for the 2B source sentences of the two updates (adv_step.fused_update)
+        return impl.fused_update(G, D, optG, optD, mk(src, c_aid), mk(tgt, 1 - c_aid), mk(gb, c_aid), c_aid, -1, T, 0.5,
+                                 2, cycle_loss_type='ml', cycle_loss_w=1.0, grad_clip=10.0, reducers=reducers)
     # the discriminator's gradient exchange + optimizer step are deferred into the generator update, where they
     # overlap the free-running generation (which does not read the discriminator)
     rd = impl.d_update(G, D, optD, mk(src, c_aid), mk(tgt, 1 - c_aid), c_aid, -1, T, 0.5, reducer=reducers[1],
@@ -179,6 +183,9 @@ def main():
     ap.add_argument('--ragged', action='store_true', help='speech-shaped sentence lengths instead of all = T')
     ap.add_argument('--batch', type=int, default=None, help='sentences per GPU (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--separate-gen', action='store_true',
+                    help='generate for the D update and for the G update in two passes of B rows (the reference\'s '
+                         'loop structure) instead of one pass of 2B rows')
     ap.add_argument('--roofline-kernel', default='sgemm_tn_128',
                     help='kernel timed with HIP events inside the timed region (default: the kernel with the '
                          'largest share of the step in profiles/: sgemm_kernel<true,false,2,2,2>)')
@@ -225,7 +232,8 @@ def main():
     elif args.workload == 'cfg2':
         run_step = lambda it, red: ml_step(impl, G, optG, batches, it, args.batch)
     else:
-        run_step = lambda it, red: adv_step(impl, G, D, optG, optD, batches, it, args.batch, red)
+        run_step = lambda it, red: adv_step(impl, G, D, optG, optD, batches, it, args.batch, red,
+                                            fused=not args.separate_gen)
     if world > 1:
         dist.barrier()
 

@@ -122,14 +122,16 @@ int a4nt_gumbel_bwd(int B, int V, const float* ds, int ldd, const float* y, int 
  * z = scale*(h W + b) + gumbel(u) (greedy: z = h W + b), per-row arg max / softmax(z/tau) statistics,
  * straight-through value, done / gen_lens bookkeeping.  One wave per 16-row x 80-column output tile
  * (v_mfma_f32_16x16x4_f32 fed from registers, no LDS), strips merged by a finalize kernel.  K must be a
- * multiple of 16, h 16-byte aligned with ldh a multiple of 4.  z [M][ldz] is saved for
+ * multiple of 16, h 16-byte aligned with ldh a multiple of 4.  z [zrows][ldz] holds rows zrow0.. of the
+ * batch (the rows whose backward pass will run; zrow0 = 0, zrows = M for all) and is saved for
  * a4nt_gumbel_bwd(inv_tau = 1/tau) (may be NULL); part is scratch of a4nt_proj_gumbel_part_floats().
  * Replaces: dec_out = p_rnn.mm(W)+b; gumbel_softmax_sample(dec_out*scale, tau); argmax; done/len
  * updates (char_translator.py:377-392) -- softmax((log_softmax(x)+g)/tau) == softmax((x+g)/tau). */
 long long a4nt_proj_gumbel_part_floats(int M, int N);
 int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh, const float* W, int ldw, const float* bias,
                          float scale, float tau, int hard, int greedy, const float* U, int ldu,
-                         unsigned long long seed, unsigned step, float* z, int ldz, float* part, float* stats,
+                         unsigned long long seed, unsigned step, float* z, int ldz, int zrow0, int zrows, float* part,
+                         float* stats,
                          long long* tok, float* val_in, float* val_out, int* gen_lens, unsigned char* done,
                          long long end_c, void* stream);
 

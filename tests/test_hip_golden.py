@@ -66,3 +66,53 @@ def test_mltrain_loss_matches_scores_path(impl):
     assert_close(loss, fx.t('loss'), TOL_OUT, 'fused CE loss')
     from golden_util import assert_grads_close
     assert_grads_close(m.named_parameters(), fx.group('grad.'), TOL_GRAD, 'fused CE')
+
+
+@pytest.mark.parametrize('name', sc.ADV_STEP)
+def test_fused_update_matches_separate_updates(impl, name):
+    """fused_update (one generation of 2B rows for both updates, BPTT kept for the generator update's rows
+    only) == d_update followed by g_update, on the fixture's weights, batches and Gumbel noise."""
+    from golden_util import Fixture, assert_close
+    fx = Fixture(name)
+    ep = fx.json('eval_params_json')
+    B = fx.t('src.inps').shape[1]
+    c_aid = int(fx.scalar('c_aid'))
+    end_c, maxlen, temp = int(fx.scalar('end_c')), int(fx.scalar('maxlen')), float(fx.scalar('temp'))
+    mk = lambda nm, a: (fx.t(nm + '.inps'), fx.t(nm + '.targs'), torch.LongTensor([a] * B), fx.np(nm + '.lens').tolist())
+    noise = fx.noise_list('cuda')
+    n_d = int(fx.scalar('n_noise_d'))
+    u_d, u_g = noise[:n_d], noise[n_d:]
+    filler = torch.full_like(noise[0], 0.5)
+    merged = [torch.cat([u_d[t] if t < len(u_d) else filler, u_g[t] if t < len(u_g) else filler], 0)
+              for t in range(max(len(u_d), len(u_g)))]
+    append = torch.zeros(1, B, fx.params['vocabulary_size'] + 1, device='cuda')
+    append[:, :, 2] = 1.0
+
+    def build():
+        G = impl.CharTranslator(fx.params)
+        G.load_state_dict({k: v.cuda() for k, v in fx.group('sdG0.').items()})
+        E = impl.CharLstm(ep) if ep.get('modeltype', 'lstm') == 'lstm' else impl.CharCNN(ep)
+        E.load_state_dict({k: v.cuda() for k, v in fx.group('sdE0.').items()})
+        return (G.train(), E.train()) + tuple(impl.make_optimizers(G, E))
+
+    G1, E1, oG1, oE1 = build()
+    G1.set_noise([u.clone() for u in noise])
+    rd1 = impl.d_update(G1, E1, oE1, mk('src', c_aid), mk('tgt', 1 - c_aid), c_aid, end_c, maxlen, temp)
+    rg1 = impl.g_update(G1, E1, oG1, mk('gb', c_aid), c_aid, end_c, maxlen, temp, append, cycle_loss_type='ml')
+    G2, E2, oG2, oE2 = build()
+    G2.set_noise(merged)
+    rd2, rg2 = impl.fused_update(G2, E2, oG2, oE2, mk('src', c_aid), mk('tgt', 1 - c_aid), mk('gb', c_aid), c_aid, end_c,
+                                 maxlen, temp, append, cycle_loss_type='ml')
+    impl.check_timeouts()
+    assert torch.equal(torch.stack(list(rd1['char_outs'])), torch.stack(list(rd2['char_outs'])))
+    assert torch.equal(torch.stack(list(rg1['char_outs'])), torch.stack(list(rg2['char_outs'])))
+    assert torch.equal(rg1['gen_lens'].cpu(), rg2['gen_lens'].cpu())
+    for k in ('loss', 'fake_logits', 'real_logits'):
+        assert_close(rd2[k], rd1[k], TOL_OUT, name + ' D ' + k)
+    for k in ('loss_gan', 'cyc_loss', 'grad_norm'):
+        assert_close(rg2[k], rg1[k], TOL_GRAD, name + ' G ' + k)
+    for (n1, p1), (_, p2) in zip(E1.named_parameters(), E2.named_parameters()):
+        assert_close(p2, p1, TOL_OUT, name + ' D weight ' + n1)
+    for (n1, p1), (_, p2) in zip(G1.named_parameters(), G2.named_parameters()):
+        assert_close(p2.grad, p1.grad, TOL_GRAD, name + ' G grad ' + n1)
+        assert_close(p2, p1, TOL_OUT, name + ' G weight ' + n1)

@@ -26,7 +26,6 @@
 // the logits never make a round trip through HBM.
 #include "gemm_stage.h"
 
-#define PG_BM 64          // rows per workgroup: wave w owns rows [16w, 16w+16)
 #define PG_BC 80          // strip width: five 16-column MFMA tiles per wave
 #define PG_DEPTH 8        // 16-k blocks in flight per wave
 
@@ -58,16 +57,19 @@ __device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+template <int RT>
 struct PgBlock {            // operands of one 16-k block
-    f32x4 a;                // A: k-steps 0..3
+    f32x4 a[RT];            // A: k-steps 0..3 of each of this wave's RT row tiles
     f32x4 b4[4];            // B of k-step i: column tiles 0..3
     float b1[4];            //                column tile 4
 };
 
-__device__ __forceinline__ void pg_load(PgBlock& blk, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned aoff,
-                                        unsigned boff, unsigned ldw_bytes, int kb, bool on) {
+template <int RT>
+__device__ __forceinline__ void pg_load(PgBlock<RT>& blk, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
+                                        const unsigned (&aoff)[RT], unsigned boff, unsigned ldw_bytes, int kb, bool on) {
     // kb: first k of the block; `on` false (past the end of K) loads nothing that is used
-    blk.a = bl4(ra, on ? aoff + (unsigned)kb * 4u : OOB);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) blk.a[r] = bl4(ra, on ? aoff[r] + (unsigned)kb * 4u : OOB);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const unsigned bo = on ? boff + (unsigned)(kb + i) * ldw_bytes : OOB;
@@ -76,42 +78,53 @@ __device__ __forceinline__ void pg_load(PgBlock& blk, __amdgpu_buffer_rsrc_t ra,
     }
 }
 
-__device__ __forceinline__ void pg_mma(const PgBlock& blk, f32x4 (&acc)[5]) {
+template <int RT>
+__device__ __forceinline__ void pg_mma(const PgBlock<RT>& blk, f32x4 (&acc)[RT][5]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[i], blk.b4[i].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[i], blk.b4[i].y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[i], blk.b4[i].z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[i], blk.b4[i].w, acc[3], 0, 0, 0);
-        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[i], blk.b1[i], acc[4], 0, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], blk.b4[i].x, acc[r][0], 0, 0, 0);
+            acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], blk.b4[i].y, acc[r][1], 0, 0, 0);
+            acc[r][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], blk.b4[i].z, acc[r][2], 0, 0, 0);
+            acc[r][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], blk.b4[i].w, acc[r][3], 0, 0, 0);
+            acc[r][4] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], blk.b1[i], acc[r][4], 0, 0, 0);
+        }
 }
 
+// RT = row tiles per wave: 1 up to 128 rows (one wave per SIMD); 2 above (256 rows: again 1008 waves, and
+// a B fragment now feeds two MFMAs, which keeps the CU's address pipe -- 4 waves x 9 loads per 16-k block --
+// below the matrix pipe's time; two waves per SIMD with RT = 1 measured 47 us against 2 x 25 us).
+template <int RT>
 __global__ __launch_bounds__(256) void proj_gumbel_kernel(ProjGumbelArgs a) {
+    constexpr int BM = 64 * RT;                              // rows per workgroup: wave w owns rows [16*RT*w, +16*RT)
     // 1-D grid; the row blocks of one strip sit 8 apart in block id (id % 8 = strip % 8), so under round-robin
     // placement they land on the same XCD and share the strip of W in that XCD's L2 (speed only)
-    const int nrb = (a.M + PG_BM - 1) / PG_BM;
+    const int nrb = (a.M + BM - 1) / BM;
     const int grp = blockIdx.x / (8 * nrb), rem = blockIdx.x % (8 * nrb);
     const int strip = grp * 8 + (rem & 7), rblk = rem >> 3;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int m0 = rblk * PG_BM + 16 * w, c0 = strip * PG_BC;
+    const int m0 = rblk * BM + 16 * RT * w, c0 = strip * PG_BC;
     if (strip >= a.nstrips || m0 >= a.M) return;             // no barriers below
 
-    // A: row m0+fr (clamped), k offset 4*fq inside a block.  B: columns c0 + 5*fr .. +4, k row 4*fq + i.
-    const int arow = min(m0 + fr, a.M - 1);
+    // A: rows m0+16r+fr (clamped), k offset 4*fq inside a block.  B: columns c0 + 5*fr .. +4, k row 4*fq + i.
     __amdgpu_buffer_rsrc_t ra = make_rsrc(a.h, clamp_bytes(((long long)(a.M - 1) * a.ldh + a.K) * 4));
     __amdgpu_buffer_rsrc_t rb = make_rsrc(a.W, clamp_bytes(((long long)(a.K - 1) * a.ldw + a.N) * 4));
-    const unsigned aoff = (unsigned)(arow * a.ldh + 4 * fq) * 4u;
+    unsigned aoff[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) aoff[r] = (unsigned)(min(m0 + 16 * r + fr, a.M - 1) * a.ldh + 4 * fq) * 4u;
     const unsigned ldw_bytes = (unsigned)a.ldw * 4u;
     const unsigned boff = (unsigned)(4 * fq) * ldw_bytes + (unsigned)(c0 + 5 * fr) * 4u;
 
-    f32x4 acc[5];
+    f32x4 acc[RT][5];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nkb = a.K >> 4;
-    PgBlock ring[PG_DEPTH];
+    PgBlock<RT> ring[PG_DEPTH];
 #pragma unroll
     for (int u = 0; u < PG_DEPTH; ++u) pg_load(ring[u], ra, rb, aoff, boff, ldw_bytes, 16 * u, u < nkb);
     for (int j0 = 0; j0 < nkb; j0 += PG_DEPTH) {
@@ -125,7 +138,9 @@ __global__ __launch_bounds__(256) void proj_gumbel_kernel(ProjGumbelArgs a) {
     }
 
     // ---- epilogue: C layout of a 16x16 tile: col = lane&15, row = 4*(lane>>4) + reg; tile c = columns c0+5*fr+c
-    const int rbase = m0 + 4 * fq;                            // rows rbase .. rbase+3 (multiple of 4)
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+    const int rbase = m0 + 16 * r + 4 * fq;                   // rows rbase .. rbase+3 (multiple of 4)
     float zv[5][4];
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(256) void proj_gumbel_kernel(ProjGumbelArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xx = acc[c][e] + bv;
+            const float xx = acc[r][c][e] + bv;
             const float zz = a.greedy ? xx : (xx * a.scale + g4[e]);
             const bool valid = cvalid && (rbase + e < a.M);
             zv[c][e] = valid ? zz : -INFINITY;
@@ -191,6 +206,7 @@ __global__ __launch_bounds__(256) void proj_gumbel_kernel(ProjGumbelArgs a) {
             float* p = a.part + ((long long)row * a.nstrips + strip) * 4;
             p[0] = m; p[1] = s; p[2] = __int_as_float(mi); p[3] = 0.f;
         }
+    }
     }
 }
 
@@ -259,10 +275,12 @@ extern "C" int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh
     a.h = h; a.ldh = ldh; a.W = W; a.ldw = ldw; a.bias = bias; a.M = M; a.N = N; a.K = K;
     a.scale = scale; a.inv_tau = greedy ? 1.f : 1.f / tau; a.greedy = greedy; a.U = U; a.ldu = ldu; a.seed = seed;
     a.step = step; a.z = z; a.ldz = ldz; a.zrow0 = zrow0; a.zrows = zrows; a.part = part; a.nstrips = (N + PG_BC - 1) / PG_BC;
-    const int nrb = (M + PG_BM - 1) / PG_BM;
+    const int rt = M > 128 ? 2 : 1;
+    const int nrb = (M + 64 * rt - 1) / (64 * rt);
     dim3 grid(((a.nstrips + 7) / 8) * 8 * nrb), block(256);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(proj_gumbel_kernel, grid, block, 0, s, a);
+    if (rt == 1) hipLaunchKernelGGL(proj_gumbel_kernel<1>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(proj_gumbel_kernel<2>, grid, block, 0, s, a);
     int rc = a4nt_check_launch("proj_gumbel");
     if (rc != A4NT_OK) return rc;
     PgFinalArgs f;

@@ -239,7 +239,7 @@ def test_conv1d_time_major(ops, K):
 
 
 @pytest.mark.parametrize('M,N,K,greedy', [(128, 10001, 512, 0), (5, 51, 64, 0), (37, 301, 96, 0), (128, 10001, 512, 1),
-                                          (130, 20000, 64, 0)])
+                                          (130, 20000, 64, 0), (256, 10001, 128, 0), (300, 777, 64, 1)])
 def test_proj_gumbel_fused(ops, M, N, K, greedy):
     """Fused projection + Gumbel sampling == (h W + b) -> reference sampler (char_translator.py:377-392)."""
     import a4nt_amd

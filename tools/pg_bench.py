@@ -14,7 +14,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 greedy = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 write_z = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 lib = _lib.load()
-M, N, K = 128, 10001, 512
+M, N, K = int(sys.argv[4]) if len(sys.argv) > 4 else 128, 10001, 512
 h = torch.randn(M, K, device='cuda')
 W = torch.randn(K, N, device='cuda') * 0.05
 b = torch.zeros(N, device='cuda')

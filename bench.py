@@ -186,9 +186,9 @@ def main():
     ap.add_argument('--separate-gen', action='store_true',
                     help='generate for the D update and for the G update in two passes of B rows (the reference\'s '
                          'loop structure) instead of one pass of 2B rows')
-    ap.add_argument('--roofline-kernel', default='sgemm_tn_128',
+    ap.add_argument('--roofline-kernel', default='sgemm_nt_128',
                     help='kernel timed with HIP events inside the timed region (default: the kernel with the '
-                         'largest share of the step in profiles/: sgemm_kernel<true,false,2,2,2>)')
+                         'largest share of the step in profiles/: sgemm_kernel<false,true,2,2,2>)')
     ap.add_argument('--no-extra-rooflines', action='store_true')
     args = ap.parse_args()
     wl = set_workload(args.workload)
@@ -273,7 +273,7 @@ def main():
     # the other MFMA kernels of the step, one untimed extra step each (outside the timed region)
     others = []
     if world == 1 and not args.no_extra_rooflines:
-        for name in ('lstm_seq_fwd', 'lstm_seq_bwd', 'proj_gumbel', 'sgemm_nt_128', 'sgemm_nn_128', 'sgemm_nt_64'):
+        for name in ('sgemm_tn_128', 'sgemm_nn_128', 'lstm_seq_fwd', 'lstm_seq_bwd', 'proj_gumbel', 'sgemm_nt_64'):
             if name == timer['name']:
                 continue
             ops.TIMER = {'name': name, 'events': []}

@@ -1,6 +1,7 @@
 """The adversarial training step over the HIP-backed modules: Py3 restatement of
 train_adversarial_translator.py:118-186 (adv_forward_pass), :433-547 (discriminator update),
-:553-735 (generator update, cycle_loss_type in {None, 'ml'}), :306-312 (optimizers), plus the batch
+:553-735 (generator update: cycle_loss_type in {None, 'ml', 'enc', 'noncyc_enc', 'bow'}, feature matching,
+ml_update), :25-38 (GradFilter), :306-312 (optimizers), plus the batch
 data-parallel gradient exchange the reference does not have (one process per GPU, RCCL all-reduce).
 
 Differences from the reference driver are structural, not numerical:
@@ -19,7 +20,7 @@ from .gen_decode import SoftSamples
 
 def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all', maxlen=100, auths=None,
                      cycle_compute=False, append_symb=None, temp=0.5, cycle_loss_type='ml', targs=None,
-                     real_batch=None, before_disc=None, gen=None):
+                     real_batch=None, before_disc=None, gen=None, grad_filter=False):
     """Returns (eval_logits [B,C] in input order, enc_out, samples (SoftSamples, generation order), gen_lens,
     char_outs[, cycle loss][, (real logits, real enc_out)]).
 
@@ -37,6 +38,8 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
             inps, lens, soft_samples=True, end_c=end_c, n_max=maxlen, temp=temp, auths=1 - auths, compact=True)
     if before_disc is not None:
         before_disc()                   # e.g. the deferred discriminator step: the generation above did not need it
+    if grad_filter:
+        samples.set_grad_filter()
     gl_host = gen_lens.cpu()
     assert int(gl_host.min()) > 0
     len_sorted, sort_idx = gl_host.sort(dim=0, descending=True, stable=True)
@@ -58,16 +61,47 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
     logits = eval_out[0].index_select(0, rev_dev)
     out = (logits, eval_out[1], samples, gen_lens, char_outs)
     if cycle_compute and backprop_for != 'eval':
+        reverse_inp = samples_srt.prepend_token(_start_id(append_symb))
         if cycle_loss_type != 'ml':
-            raise NotImplementedError('cycle_loss_type %r is a section-8(f) "next" row' % cycle_loss_type)
-        start_id = int(append_symb) if not torch.is_tensor(append_symb) else int(append_symb[0, 0].argmax())
-        reverse_inp = samples_srt.prepend_token(start_id)
-        cyc = modelGen.forward_mltrain_loss(reverse_inp, len_sorted.tolist(), inps, lens, targs, auths=auths,
-                                            adv_inp=True, sort_enc=rev_dev)
-        out = out + (cyc,)
+            # reverse translation: a second, differentiable free-running generation from the soft samples (:165-174)
+            rev, rev_lens, rev_chars = modelGen.forward_advers_gen(
+                reverse_inp, len_sorted.tolist(), soft_samples=True, end_c=end_c, n_max=maxlen, temp=temp, auths=auths,
+                adv_inp=True, compact=True)
+            if grad_filter:
+                rev.set_grad_filter()
+            out = out + (rev.index_select_batch(rev_dev), rev_lens.index_select(0, rev_dev),
+                         [rc.index_select(0, rev_dev) for rc in rev_chars])
+        else:
+            cyc = modelGen.forward_mltrain_loss(reverse_inp, len_sorted.tolist(), inps, lens, targs, auths=auths,
+                                                adv_inp=True, sort_enc=rev_dev)
+            out = out + (cyc,)
     if real_batch is not None:
         out = out + (real_out,)
     return out
+
+
+def _start_id(append_symb):
+    """append_symb: the reference's one-hot [1,B,V] start row (train_adversarial_translator.py:158), or the id."""
+    return int(append_symb) if not torch.is_tensor(append_symb) else int(append_symb[0, 0].argmax())
+
+
+def _sorted_encode(encoder, samples, lens_dev, start_id):
+    """Semantic encoding of generated samples: sort by length, prepend the start row, encode, undo the sort
+    (train_adversarial_translator.py:631-638, 651-658)."""
+    gl = lens_dev.cpu()
+    len_sorted, sort_idx = gl.sort(dim=0, descending=True, stable=True)
+    _, rev_idx = sort_idx.sort(dim=0)
+    dev = samples.val.device
+    enc_inp = samples.index_select_batch(sort_idx.to(dev)).prepend_token(start_id)
+    rev_enc = encoder.forward_encode(enc_inp, len_sorted.tolist(), adv_inp=True)
+    return rev_enc.index_select(0, rev_idx.to(dev))
+
+
+def _cycle_loss_fn(kind):
+    """train_adversarial_translator.py:324: CosineEmbeddingLoss(margin=0.1) against ones, or L1."""
+    if kind == 'cosine':
+        return lambda a, b: F.cosine_embedding_loss(a, b, torch.ones(a.shape[0], device=a.device), margin=0.1)
+    return F.l1_loss
 
 
 def make_optimizers(modelGen, modelEval, lr_gen=1e-4, lr_eval=1e-3, decay_rate=0.99, smooth_eps=1e-8):
@@ -272,8 +306,16 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
 
 
 def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, append_symb, cycle_loss_type='ml',
-             cycle_loss_w=1.0, grad_clip=10.0, step=True, reducer=None, before_disc=None, gen=None):
-    """One generator update (:553-735): 5*BCE(fake, 1) + w * CE reconstruction, clip_grad_norm, RMSprop.
+             cycle_loss_w=1.0, grad_clip=10.0, step=True, reducer=None, before_disc=None, gen=None,
+             modelGenEncoder=None, cycle_loss_func='l1', grad_filter=False, feature_matching=None, weigh_feat_match=0,
+             ml_update=0, tgt_batch=None):
+    """One generator update (:553-735): 5*BCE(fake, 1) + cycle loss [+ feature matching], clip_grad_norm, RMSprop.
+
+    cycle_loss_type: 'ml' (reconstruction CE through the teacher-forced pass), 'enc' (semantic encoder of the
+    input vs. of the reverse translation), 'noncyc_enc' (vs. of the generated sentence), 'bow' (bag of words of
+    the input vs. the time-summed reverse samples) or None.  modelGenEncoder: frozen CharTranslator(encoder_only=True)
+    for the two encoder losses; cycle_loss_func 'l1' | 'cosine'.  feature_matching / ml_update use tgt_batch, a
+    batch of the target author (:572-591).  grad_filter: the driver's GradFilter on both sample tensors.
     before_disc: callable run after the generation forward and before the discriminator is used
     (the deferred tail of d_update)."""
     _set_requires_grad(modelEval, False)
@@ -282,19 +324,65 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
         optimGen.zero_grad()
     modelGen.train()
     inps, targs, auths, lens = batch
+    ml_loss, targ_mean_vec = None, None
+    if feature_matching or ml_update:
+        gt_inps, gt_targs, gt_auths, gt_lens = tgt_batch
+        if before_disc is not None:
+            before_disc()
+            before_disc = None
+        if feature_matching:
+            eval_out_gt = modelEval.forward_classify(gt_targs, lens=gt_lens, drop=False)
+            if weigh_feat_match:
+                w = -F.log_softmax(eval_out_gt[0], dim=1)[:, 1 - c_aid]
+                w = w / w.sum()
+                targ_mean_vec = (eval_out_gt[1] * w[:, None]).sum(dim=0).detach()
+            else:
+                targ_mean_vec = eval_out_gt[1].mean(dim=0).detach()
+        if ml_update:
+            ml_loss = ml_update * modelGen.forward_mltrain_loss(gt_inps, gt_lens, gt_inps, gt_lens, gt_targs,
+                                                                auths=gt_auths)
+            ml_loss.backward()
     outs = adv_forward_pass(modelGen, modelEval, inps, lens, end_c=end_c, maxlen=maxlen, auths=auths,
-                            cycle_compute=(cycle_loss_type is not None), append_symb=append_symb, temp=temp,
-                            cycle_loss_type=cycle_loss_type, targs=targs, before_disc=before_disc, gen=gen)
+                            cycle_compute=(cycle_loss_type is not None and cycle_loss_type != 'noncyc_enc'),
+                            append_symb=append_symb, temp=temp, cycle_loss_type=cycle_loss_type, targs=targs,
+                            before_disc=before_disc, gen=gen, grad_filter=grad_filter)
+    dev = outs[0].device
+    fm_loss = torch.zeros((), device=dev)
+    if feature_matching:
+        fm_loss = feature_matching * F.l1_loss(outs[1].mean(dim=0), targ_mean_vec)
+    loss_fn = _cycle_loss_fn(cycle_loss_func)
+    rev_out = None
     if cycle_loss_type == 'ml':
         w_tok = reducer.token_weight(sum(int(l) for l in lens)) if reducer is not None else 1.0
         cyc_loss = cycle_loss_w * w_tok * outs[-1]
+    elif cycle_loss_type == 'bow':
+        rev, rev_lens, rev_chars = outs[-3], outs[-2], outs[-1]
+        cyc_targ = torch.zeros(targs.shape[1], rev.vocab, device=dev).scatter_add_(
+            1, targs.t().to(dev), torch.ones(targs.shape[::-1], device=dev))
+        cyc_targ[:, 0] = 0
+        cyc_loss = cycle_loss_w * loss_fn(rev.to_dense().sum(dim=0), cyc_targ)
+        rev_out = (rev_lens, rev_chars)
+    elif cycle_loss_type == 'noncyc_enc':
+        with torch.no_grad():
+            enc_gt = modelGenEncoder.forward_encode(inps, lens)
+        rev_enc = _sorted_encode(modelGenEncoder, outs[2], outs[3], _start_id(append_symb))
+        cyc_loss = cycle_loss_w * loss_fn(rev_enc, enc_gt)
+    elif cycle_loss_type == 'enc':
+        with torch.no_grad():
+            enc_gt = modelGenEncoder.forward_encode(inps, lens)
+        rev, rev_lens, rev_chars = outs[-3], outs[-2], outs[-1]
+        rev_enc = _sorted_encode(modelGenEncoder, rev, rev_lens, _start_id(append_symb))
+        cyc_loss = cycle_loss_w * loss_fn(rev_enc, enc_gt)
+        rev_out = (rev_lens, rev_chars)
+    elif cycle_loss_type is None:
+        cyc_loss = torch.zeros((), device=dev)
     else:
-        cyc_loss = torch.zeros((), device=outs[0].device)
+        raise NotImplementedError('cycle_loss_type %r' % (cycle_loss_type,))
     targ_aid = 1 - c_aid
     gen_aid_out = outs[0][:, targ_aid]
     loss_gan = 5.0 * F.binary_cross_entropy_with_logits(gen_aid_out, torch.ones_like(gen_aid_out))
     err = (gen_aid_out.detach() > 0.).float().mean()
-    loss_tot = loss_gan + cyc_loss
+    loss_tot = loss_gan + cyc_loss + fm_loss
     if reducer is not None:
         reducer.arm()
     loss_tot.backward()
@@ -304,9 +392,14 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
     gnorm = torch.nn.utils.clip_grad_norm_(modelGen.parameters(), grad_clip)
     if step:
         optimGen.step()
-    return {'loss': loss_tot.detach(), 'loss_gan': loss_gan.detach(), 'cyc_loss': cyc_loss.detach(),
-            'grad_norm': gnorm.detach(), 'err': err, 'gen_lens': outs[3], 'char_outs': outs[4],
-            'fake_logits': outs[0].detach()}
+    res = {'loss': loss_tot.detach(), 'loss_gan': loss_gan.detach(), 'cyc_loss': cyc_loss.detach(),
+           'fm_loss': fm_loss.detach(), 'grad_norm': gnorm.detach(), 'err': err, 'gen_lens': outs[3],
+           'char_outs': outs[4], 'fake_logits': outs[0].detach()}
+    if ml_loss is not None:
+        res['ml_loss'] = ml_loss.detach()
+    if rev_out is not None:
+        res['rev_gen_lens'], res['rev_char_outs'] = rev_out
+    return res
 
 
 def fused_update(modelGen, modelEval, optimGen, optimEval, src_batch, tgt_batch, gen_batch, c_aid, end_c, maxlen, temp,
@@ -323,6 +416,15 @@ def fused_update(modelGen, modelEval, optimGen, optimEval, src_batch, tgt_batch,
     g_inps, _, g_auths, g_lens = gen_batch
     B = s_inps.shape[1]
     assert g_inps.shape == s_inps.shape
+    from . import ops
+    if not ops.lstm_rows_fit(2 * B, modelGen.dec_hidden_size):
+        # 2B rows exceed one persistent sweep at this hidden size: two passes of B rows, as the reference does
+        rd = d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c, maxlen, temp, step=step,
+                      reducer=reducers[1], defer=True)
+        rg = g_update(modelGen, modelEval, optimGen, gen_batch, c_aid, end_c, maxlen, temp, append_symb,
+                      cycle_loss_type=cycle_loss_type, cycle_loss_w=cycle_loss_w, grad_clip=grad_clip, step=step,
+                      reducer=reducers[0], before_disc=rd.pop('finish'))
+        return rd, rg
     _set_requires_grad(modelGen, True)
     optimGen.zero_grad()
     modelGen.train()

@@ -265,8 +265,11 @@ class CharTranslator(nn.Module):
         if soft_samples:
             self.temp = temp
         dec = self._decoder(auths)
-        fused = (self.dec_num_rec_layers == 1 and not soft_in and n_samples == 1 and not self.learn_gumbel and
-                 (self.gumb_type or not soft_samples))
+        # a SoftSamples input whose first row is a constant start token (prepend_token) needs no gradient for
+        # the decoder's first input, so it can take the fused loop too (the reverse translation of the cycle losses)
+        first_const = isinstance(x, SoftSamples) and x.const_rows >= 1
+        fused = (self.dec_num_rec_layers == 1 and (not soft_in or first_const) and n_samples == 1 and
+                 not self.learn_gumbel and (self.gumb_type or not soft_samples))
         if not fused:
             if grad_rows is not None:
                 raise NotImplementedError('grad_rows needs the fused generation path')
@@ -276,7 +279,8 @@ class CharTranslator(nn.Module):
         cfg = dict(n_max=n_max, end_c=int(end_c), tau=float(temp), scale=float(self.softmax_scale),
                    hard=bool(self.gumb_type), greedy=not soft_samples, need_grad=need_grad, noise=self._noise,
                    seed=self.noise_seed, step0=self._noise_step, grad_rows=grad_rows)
-        samples, gen_lens, tok = gen_decode(ctxt, x[0].to(dev), self.char_emb.weight, w_ih, w_hh, b_ih, b_hh,
+        tok0 = x.tok[0] if isinstance(x, SoftSamples) else x[0].to(dev)
+        samples, gen_lens, tok = gen_decode(ctxt, tok0, self.char_emb.weight, w_ih, w_hh, b_ih, b_hh,
                                             dec[1], dec[2], cfg)
         self._noise_step += n_max
         char_out = list(tok.unbind(0))

@@ -30,6 +30,7 @@ class _GenHandle(object):
     def __init__(self):
         self.contribs = []        # (demb [n,B,E], W [V,E]) registered by consumers' backward
         self.dense_grads = []     # dense d(sample) [n,B,V] (API path that materialised the samples)
+        self.grad_filter = False  # GradFilter of the reference driver (train_adversarial_translator.py:25-38)
 
 
 class SoftSamples(object):
@@ -41,8 +42,9 @@ class SoftSamples(object):
     from generator step t - t_offset, generator batch column perm[b].
     """
 
-    def __init__(self, tok, val, vocab, origin=None):
+    def __init__(self, tok, val, vocab, origin=None, const_rows=0):
         self.tok, self.val, self.vocab, self.origin = tok, val, vocab, origin
+        self.const_rows = const_rows      # leading rows that are constant one-hot rows (prepend_token)
 
     @property
     def shape(self):
@@ -60,7 +62,8 @@ class SoftSamples(object):
         if self.origin is not None:
             h, off, perm = self.origin
             origin = (h, off, idx if perm is None else perm.index_select(0, idx))
-        return SoftSamples(self.tok.index_select(1, idx), self.val.index_select(1, idx), self.vocab, origin)
+        return SoftSamples(self.tok.index_select(1, idx), self.val.index_select(1, idx), self.vocab, origin,
+                           self.const_rows)
 
     def prepend_token(self, token_id):
         """torch.cat([one_hot(start), samples]) of the reference (train_adversarial_translator.py:158)."""
@@ -71,7 +74,15 @@ class SoftSamples(object):
         if self.origin is not None:
             h, off, perm = self.origin
             origin = (h, off + 1, perm)
-        return SoftSamples(torch.cat([t0, self.tok]), torch.cat([v0, self.val]), self.vocab, origin)
+        return SoftSamples(torch.cat([t0, self.tok]), torch.cat([v0, self.val]), self.vocab, origin,
+                           self.const_rows + 1)
+
+    def set_grad_filter(self):
+        """The reference's GradFilter on this sample tensor: its backward keeps, per batch column, only the
+        time step whose gradient has the largest absolute sum over the vocabulary."""
+        if self.origin is not None:
+            self.origin[0].grad_filter = True
+        return self
 
     def rows(self, r0, r1, n=None, differentiable=True):
         """Batch columns [r0, r1) and the first n steps.  With differentiable=True the result keeps this
@@ -260,6 +271,9 @@ class _GenDecode(Function):
         if first:
             S.zero_()
         handle.contribs, handle.dense_grads = [], []
+        if handle.grad_filter:
+            _, top = S.abs().sum(dim=-1).topk(1, dim=0)                       # [1,B]: one time step per column
+            S.mul_(torch.zeros((n, B), device=dev).scatter_(0, top, 1.0).unsqueeze(-1))
         w_ic = w_ih[:, :Hc]
         w_ie = w_ih[:, Hc:].contiguous()
         Wcat = torch.cat([w_hh, w_ie], dim=1).contiguous()             # [4H, H+E]

@@ -256,6 +256,12 @@ def _lstm_ws(dev, B, H, backward):
     return _ws[key]
 
 
+def lstm_rows_fit(B, H):
+    """True when a batch of B rows fits one persistent sweep at hidden size H."""
+    mt, g = ctypes.c_int(0), ctypes.c_int(0)
+    return _lib.load().a4nt_lstm_geometry(int(B), int(H), ctypes.byref(mt), ctypes.byref(g)) == 0
+
+
 def lstm_set_max_workgroups(n):
     """256: one persistent-sweep workgroup per CU (leaves register space for kernels of other streams,
     e.g. RCCL under data parallelism); 512 (default): two per CU where the geometry allows it."""
@@ -397,8 +403,22 @@ class _LstmLayer(Function):
 
 
 def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, lens_dev=None, h0=None, c0=None, gc=None):
-    """Returns (out [T,B,H] zero-padded past each row's length, hN [B,H], cN [B,H])."""
-    return _LstmLayer.apply(_f32(x, 'lstm input').contiguous(), w_ih, w_hh, b_ih, b_hh, h0, c0, gc, lens_dev)
+    """Returns (out [T,B,H] zero-padded past each row's length, hN [B,H], cN [B,H]).
+    A batch larger than one persistent sweep holds (512 rows at H = 512, 256 at H = 1024) runs as several
+    sweeps over row chunks: rows are independent."""
+    x = _f32(x, 'lstm input')
+    B, H = x.shape[1], w_hh.shape[1]
+    if lstm_rows_fit(B, H):
+        return _LstmLayer.apply(x.contiguous(), w_ih, w_hh, b_ih, b_hh, h0, c0, gc, lens_dev)
+    step = B
+    while step > 1 and not lstm_rows_fit(step, H):
+        step = (step + 1) // 2
+    step = max(16, step // 16 * 16)
+    sl = lambda t_, a, b: None if t_ is None else t_[a:b]
+    parts = [_LstmLayer.apply(x[:, a:a + step].contiguous(), w_ih, w_hh, b_ih, b_hh, sl(h0, a, a + step),
+                              sl(c0, a, a + step), sl(gc, a, a + step), sl(lens_dev, a, a + step))
+             for a in range(0, B, step)]
+    return (torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 0), torch.cat([p[2] for p in parts], 0))
 
 
 class _Embed(Function):

@@ -6,7 +6,9 @@ hot path:
 
   * adv_forward_pass     train_adversarial_translator.py:118-186
   * d_update             train_adversarial_translator.py:433-547   (non-WGAN, maximize_entropy == 0)
-  * g_update             train_adversarial_translator.py:553-735   (cycle_loss_type in {None, 'ml'})
+  * g_update             train_adversarial_translator.py:553-735   (cycle_loss_type in {None, 'ml', 'enc',
+                         'noncyc_enc', 'bow'}, feature matching :572-585,609-613, ml_update :587-591)
+  * GradFilter           train_adversarial_translator.py:25-38
   * make_optimizers      train_adversarial_translator.py:306-312
 
 The functions are model-agnostic: they only use the nn.Module API of section 8(b), so the golden
@@ -24,8 +26,25 @@ def _accepts_drop(model):
     return 'drop' in inspect.signature(model.forward_classify).parameters
 
 
+class GradFilter(torch.autograd.Function):
+    """Identity whose backward keeps the gradient of ONE time step per batch column, the one with the largest
+    absolute sum over the vocabulary (train_adversarial_translator.py:25-38; the reference stores topk = 1
+    whatever its argument is, :28)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        n_time, b_sz = grad_output.shape[:2]
+        _, topkidx = grad_output.abs().sum(dim=-1).topk(1, dim=0)
+        mask = torch.zeros(n_time, b_sz, device=grad_output.device).scatter_(0, topkidx, 1.)
+        return grad_output * mask.unsqueeze(-1)
+
+
 def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all', maxlen=100, auths=None,
-                     cycle_compute=False, append_symb=None, temp=0.5, cycle_loss_type='enc'):
+                     cycle_compute=False, append_symb=None, temp=0.5, cycle_loss_type='enc', grad_filter=False):
     if backprop_for in ('eval', 'None'):
         modelGen.eval()
     else:
@@ -37,6 +56,8 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
     len_sorted, sort_idx = gen_lens.sort(dim=0, descending=True)
     _, rev_sort_idx = sort_idx.sort(dim=0)
     gen_samples_tensor = torch.stack(list(gen_samples), dim=0)
+    if grad_filter:
+        gen_samples_tensor = GradFilter.apply(gen_samples_tensor)
     gen_samples_srt = gen_samples_tensor.index_select(1, sort_idx)
     if backprop_for == 'eval':
         gen_samples_srt = gen_samples_srt.detach()
@@ -51,6 +72,8 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
                 reverse_inp, len_sorted.tolist(), soft_samples=True, end_c=end_c, n_max=maxlen, temp=temp,
                 auths=auths, adv_inp=True)
             rev_s = torch.stack(list(rev_s), dim=0).index_select(1, rev_sort_idx)
+            if grad_filter:
+                rev_s = GradFilter.apply(rev_s)
             rev_lens = rev_lens.index_select(0, rev_sort_idx)
             rev_chars = [rc.index_select(0, rev_sort_idx) for rc in rev_chars]
             samples_out = (gen_samples_tensor, gen_lens, char_outs, rev_s, rev_lens, rev_chars)
@@ -110,35 +133,99 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
             'gen_lens': outs[3], 'char_outs': outs[4]}
 
 
+def _cycle_loss_fn(kind):
+    """train_adversarial_translator.py:324."""
+    if kind == 'cosine':
+        cos = nn.CosineEmbeddingLoss(margin=0.1)
+        return lambda a, b: cos(a, b, torch.ones(a.shape[0], device=a.device))
+    return nn.L1Loss()
+
+
 def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, append_symb,
-             cycle_loss_type='ml', cycle_loss_w=1.0, grad_clip=10.0, step=True):
-    """One generator update (:553-735)."""
+             cycle_loss_type='ml', cycle_loss_w=1.0, grad_clip=10.0, step=True, modelGenEncoder=None,
+             cycle_loss_func='l1', grad_filter=False, feature_matching=None, weigh_feat_match=0, ml_update=0,
+             tgt_batch=None):
+    """One generator update (:553-735).  tgt_batch: a batch of the target author (feature matching / ml_update)."""
     _set_requires_grad(modelEval, False)
     _set_requires_grad(modelGen, True)
     optimGen.zero_grad()
     modelGen.train()
     inps, targs, auths, lens = batch
+    ml_loss = None
+    if feature_matching or ml_update:
+        gt_inps, gt_targs, gt_auths, gt_lens = tgt_batch
+        if feature_matching:
+            kw = {'drop': False} if _accepts_drop(modelEval) else {}
+            eval_out_gt = modelEval.forward_classify(gt_targs, lens=gt_lens, **kw)
+            if weigh_feat_match:
+                w = -nn.functional.log_softmax(eval_out_gt[0], dim=1)[:, 1 - c_aid]
+                w = w / w.sum()
+                targ_mean_vec = (eval_out_gt[1] * w[:, None]).sum(dim=0).detach()
+            else:
+                targ_mean_vec = eval_out_gt[1].mean(dim=0).detach()
+        if ml_update:
+            ml_out, _ = modelGen.forward_mltrain(gt_inps, gt_lens, gt_inps, gt_lens, auths=gt_auths)
+            ml_targ = pack_padded_sequence(gt_targs.to(ml_out.device), gt_lens)
+            ml_loss = ml_update * nn.functional.cross_entropy(pack_padded_sequence(ml_out, gt_lens)[0], ml_targ[0])
+            ml_loss.backward()
     outs = adv_forward_pass(modelGen, modelEval, inps, lens, end_c=end_c, maxlen=maxlen, auths=auths,
-                            cycle_compute=(cycle_loss_type is not None), append_symb=append_symb, temp=temp,
-                            cycle_loss_type=cycle_loss_type)
+                            cycle_compute=(cycle_loss_type is not None and cycle_loss_type != 'noncyc_enc'),
+                            append_symb=append_symb, temp=temp, cycle_loss_type=cycle_loss_type, grad_filter=grad_filter)
     dev = outs[0].device
+    fm_loss = torch.zeros((), device=dev)
+    if feature_matching:
+        fm_loss = feature_matching * nn.functional.l1_loss(outs[1].mean(dim=0), targ_mean_vec)
+    loss_fn = _cycle_loss_fn(cycle_loss_func)
+    rev_lens_out, rev_chars_out = None, None
     if cycle_loss_type == 'ml':
         rev_ml = outs[-1]
         targ_p = pack_padded_sequence(targs.to(dev), lens)
         cyc_loss = cycle_loss_w * nn.functional.cross_entropy(pack_padded_sequence(rev_ml, lens)[0], targ_p[0])
+    elif cycle_loss_type == 'bow':
+        # bag of words of the input sentence against the time-summed reverse samples (:617-625)
+        b_sz = targs.shape[1]
+        cyc_targ = torch.zeros(b_sz, append_symb.shape[-1], device=dev).scatter_add_(
+            1, targs.t().to(dev), torch.ones(targs.shape[::-1], device=dev))
+        cyc_targ[:, 0] = 0
+        cyc_loss = cycle_loss_w * loss_fn(outs[-3].sum(dim=0), cyc_targ)
+        rev_lens_out, rev_chars_out = outs[-2], outs[-1]
+    elif cycle_loss_type == 'noncyc_enc':
+        # semantic encoder of the input vs. of the generated sentence (:626-643)
+        enc_inp_gt = modelGenEncoder.forward_encode(inps, lens)
+        gen_samples, gen_lens = outs[2], outs[3]
+        len_sorted, sort_idx = gen_lens.sort(dim=0, descending=True)
+        _, rev_sort_idx = sort_idx.sort(dim=0)
+        enc_inp = torch.cat([append_symb, gen_samples.index_select(1, sort_idx)])
+        rev_enc = modelGenEncoder.forward_encode(enc_inp, len_sorted.tolist(), adv_inp=True)
+        cyc_loss = cycle_loss_w * loss_fn(rev_enc.index_select(0, rev_sort_idx), enc_inp_gt.detach())
+    elif cycle_loss_type == 'enc':
+        # semantic encoder of the input vs. of the reverse translation of the generated sentence (:644-660)
+        enc_inp_gt = modelGenEncoder.forward_encode(inps, lens)
+        rev_samples, rev_gen_lens = outs[-3], outs[-2]
+        len_sorted, sort_idx = rev_gen_lens.sort(dim=0, descending=True)
+        _, rev_sort_idx = sort_idx.sort(dim=0)
+        enc_inp = torch.cat([append_symb, rev_samples.index_select(1, sort_idx)])
+        rev_enc = modelGenEncoder.forward_encode(enc_inp, len_sorted.tolist(), adv_inp=True)
+        cyc_loss = cycle_loss_w * loss_fn(rev_enc.index_select(0, rev_sort_idx), enc_inp_gt.detach())
+        rev_lens_out, rev_chars_out = outs[-2], outs[-1]
     elif cycle_loss_type is None:
         cyc_loss = torch.zeros((), device=dev)
     else:
-        raise NotImplementedError('oracle: cycle_loss_type %r is a section-8(f) "next" row' % cycle_loss_type)
+        raise NotImplementedError('oracle: cycle_loss_type %r' % cycle_loss_type)
     targ_aid = 1 - c_aid
     gen_aid_out = outs[0][:, targ_aid]
     loss_gan = 5.0 * nn.functional.binary_cross_entropy_with_logits(gen_aid_out, torch.ones_like(gen_aid_out))
     err = (gen_aid_out.detach() > 0.).float().mean()
-    loss_tot = loss_gan + cyc_loss
+    loss_tot = loss_gan + cyc_loss + fm_loss
     loss_tot.backward()
     gnorm = torch.nn.utils.clip_grad_norm_(modelGen.parameters(), grad_clip)
     if step:
         optimGen.step()
-    return {'loss': loss_tot.detach(), 'loss_gan': loss_gan.detach(), 'cyc_loss': cyc_loss.detach(),
-            'grad_norm': gnorm.detach() if torch.is_tensor(gnorm) else torch.tensor(gnorm), 'err': err,
-            'gen_lens': outs[3], 'char_outs': outs[4], 'fake_logits': outs[0].detach()}
+    res = {'loss': loss_tot.detach(), 'loss_gan': loss_gan.detach(), 'cyc_loss': cyc_loss.detach(),
+           'fm_loss': fm_loss.detach(), 'grad_norm': gnorm.detach() if torch.is_tensor(gnorm) else torch.tensor(gnorm),
+           'err': err, 'gen_lens': outs[3], 'char_outs': outs[4], 'fake_logits': outs[0].detach()}
+    if ml_loss is not None:
+        res['ml_loss'] = ml_loss.detach()
+    if rev_lens_out is not None:
+        res['rev_gen_lens'], res['rev_char_outs'] = rev_lens_out, rev_chars_out
+    return res

@@ -462,6 +462,64 @@ def fx_adv_step(ct, cl, cc):
         save(name, gp, **arrs)
 
 
+def fx_gstep_variants(ct, cl):
+    """Generator update with the other cycle / semantic losses of the reference driver:
+    'noncyc_enc', 'enc' (second, soft-input generation; cosine loss; GradFilter), 'bow' (+ feature matching,
+    weighted, + ml_update).  Reference model classes driven by oracle/adv_step.py."""
+    from oracle import adv_step
+    cases = (('gstep_noncyc', dict(cycle_loss_type='noncyc_enc', cycle_loss_func='l1')),
+             ('gstep_enc_cos_gf', dict(cycle_loss_type='enc', cycle_loss_func='cosine', grad_filter=True)),
+             ('gstep_bow_fm_ml', dict(cycle_loss_type='bow', feature_matching=0.5, weigh_feat_match=1, ml_update=0.7)))
+    for name, kw in cases:
+        g = torch.Generator().manual_seed(71)
+        torch.manual_seed(14)
+        gp = gen_params()
+        modelGen = ct.CharTranslator(gp)
+        scale_weights(modelGen, 300.0)
+        ep = eval_params()
+        modelEval = cl.CharLstm(ep)
+        enc = None
+        if kw['cycle_loss_type'] in ('enc', 'noncyc_enc'):
+            enc = ct.CharTranslator(gp, encoder_only=True)
+            st = enc.state_dict()
+            for k, v in modelGen.state_dict().items():
+                if k in st:
+                    st[k] = v.clone()
+            enc.load_state_dict(st)
+            enc.train()
+            for p_ in enc.parameters():
+                p_.requires_grad = False
+        modelGen.train()
+        modelEval.train()
+        optG, optE = adv_step.make_optimizers(modelGen, modelEval)
+        T, B = 7, 6
+        gb = synth_batch(g, T, B, V0)
+        tgt = synth_batch(g, T, B, V0)
+        c_aid = 0
+        mk = lambda b, a: (b[0], b[1], torch.LongTensor([a] * B), b[2])
+        end_c, maxlen, temp = 1, T, 0.5
+        append = torch.zeros(1, B, V0 + 1)
+        append[:, :, 2] = 1.0
+        arrs = {}
+        arrs.update(sd_np(modelGen, 'sdG0.'))
+        arrs.update(sd_np(modelEval, 'sdE0.'))
+        noise = Noise(91)
+        ct.sample_gumbel = noise.sample_gumbel
+        rg = adv_step.g_update(modelGen, modelEval, optG, mk(gb, c_aid), c_aid, end_c, maxlen, temp, append,
+                               cycle_loss_w=1.0, grad_clip=10.0, step=False, modelGenEncoder=enc,
+                               tgt_batch=mk(tgt, 1 - c_aid), **kw)
+        arrs.update(grads_np(modelGen, 'gradG.'))
+        for k, v in rg.items():
+            arrs['g.' + k] = torch.stack(list(v), 0) if isinstance(v, list) else v
+        for nm, b in (('gb', gb), ('tgt', tgt)):
+            arrs[nm + '.inps'], arrs[nm + '.targs'], arrs[nm + '.lens'] = b[0], b[1], np.array(b[2])
+        for i, u in enumerate(noise.drawn):
+            arrs['u%d' % i] = u
+        arrs.update(dict(n_noise=len(noise.drawn), c_aid=c_aid, end_c=end_c, maxlen=maxlen, temp=temp,
+                         eval_params_json=np.array(json.dumps(ep)), step_kwargs_json=np.array(json.dumps(kw))))
+        save(name, gp, **arrs)
+
+
 def fx_init(ct, cl):
     torch.manual_seed(10)
     m = ct.CharTranslator(gen_params())
@@ -477,7 +535,11 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['options']:           # only the fixtures added after the first set
         fx_translator_options(ct)
         sys.exit(0)
+    if sys.argv[1:] == ['gstep']:
+        fx_gstep_variants(ct, cl)
+        sys.exit(0)
     fx_translator_options(ct)
+    fx_gstep_variants(ct, cl)
     fx_gumbel(ct)
     fx_translator_mltrain(ct)
     fx_advers_gen(ct)

@@ -15,6 +15,7 @@ GEN_SOFT = ['gen_soft_plain', 'gen_soft_res2', 'gen_soft_split', 'gen_soft_learn
 CLF_LSTM = ['clf_lstm_mp0', 'clf_lstm_mp1', 'clf_lstm_mp2', 'clf_lstm_res']
 CLF_CNN = ['clf_cnn_234', 'clf_cnn_43', 'clf_cnn_3layer_res']
 ADV_STEP = ['adv_step_lstm', 'adv_step_cnn']
+GSTEP = ['gstep_noncyc', 'gstep_enc_cos_gf', 'gstep_bow_fm_ml']
 
 
 def _load(model, sd, device):
@@ -180,3 +181,47 @@ def run_adv_step(impl, device, name, tol_out, tol_grad, step_mod=None, tol_weigh
     optG.step()
     for k, v in fx.group('sdG1.').items():
         assert_close(G.state_dict()[k], v, tol_weights, name + ' G weights after step: ' + k)
+
+
+def run_gstep_variant(impl, device, name, tol_out, tol_grad, step_mod=None):
+    """Generator update with the 'noncyc_enc' / 'enc' / 'bow' cycle losses, feature matching, ml_update and
+    GradFilter (train_adversarial_translator.py:572-591, 609-660, 25-38) on the fixture's weights and noise."""
+    fx = Fixture(name)
+    step_mod = step_mod or impl
+    kw = fx.json('step_kwargs_json')
+    ep = fx.json('eval_params_json')
+    G = _load(impl.CharTranslator(fx.params), fx.group('sdG0.'), device).train()
+    E = _load(impl.CharLstm(ep), fx.group('sdE0.'), device).train()
+    enc = None
+    if kw['cycle_loss_type'] in ('enc', 'noncyc_enc'):
+        enc = impl.CharTranslator(fx.params, encoder_only=True).to(device)
+        st = enc.state_dict()
+        for k, v in G.state_dict().items():
+            if k in st:
+                st[k] = v.clone()
+        enc.load_state_dict(st)
+        enc.train()
+        for p in enc.parameters():
+            p.requires_grad = False
+    optG, _ = step_mod.make_optimizers(G, E)
+    G.set_noise(fx.noise_list(device))
+    B = fx.t('gb.inps').shape[1]
+    c_aid = int(fx.scalar('c_aid'))
+    end_c, maxlen, temp = int(fx.scalar('end_c')), int(fx.scalar('maxlen')), float(fx.scalar('temp'))
+    mk = lambda nm, a: (fx.t(nm + '.inps'), fx.t(nm + '.targs'), torch.LongTensor([a] * B), fx.np(nm + '.lens').tolist())
+    append = torch.zeros(1, B, fx.params['vocabulary_size'] + 1, device=device)
+    append[:, :, 2] = 1.0
+    rg = step_mod.g_update(G, E, optG, mk('gb', c_aid), c_aid, end_c, maxlen, temp, append, cycle_loss_w=1.0,
+                           grad_clip=10.0, step=False, modelGenEncoder=enc, tgt_batch=mk('tgt', 1 - c_aid), **kw)
+    assert torch.equal(torch.stack(list(rg['char_outs']), 0).cpu().long(), fx.t('g.char_outs').long())
+    assert torch.equal(rg['gen_lens'].cpu().long(), fx.t('g.gen_lens').long())
+    if 'g.rev_char_outs' in fx:
+        assert torch.equal(torch.stack(list(rg['rev_char_outs']), 0).cpu().long(), fx.t('g.rev_char_outs').long())
+        assert torch.equal(rg['rev_gen_lens'].cpu().long(), fx.t('g.rev_gen_lens').long())
+    for k in ('loss_gan', 'cyc_loss', 'fm_loss', 'loss'):
+        if float(fx.t('g.' + k).abs().max()) > 0:
+            assert_close(rg[k], fx.t('g.' + k), tol_out, name + ' ' + k)
+    if 'g.ml_loss' in fx:
+        assert_close(rg['ml_loss'], fx.t('g.ml_loss'), tol_out, name + ' ml_loss')
+    assert_close(rg['grad_norm'], fx.t('g.grad_norm'), tol_grad, name + ' grad norm')
+    assert_grads_close(G.named_parameters(), fx.group('gradG.'), tol_grad, name + ' G')

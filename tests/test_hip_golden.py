@@ -51,6 +51,12 @@ def test_adv_step(impl, name):
     impl.check_timeouts()
 
 
+@pytest.mark.parametrize('name', sc.GSTEP)
+def test_gstep_variants(impl, name):
+    sc.run_gstep_variant(impl, 'cuda', name, TOL_OUT, TOL_GRAD)
+    impl.check_timeouts()
+
+
 def test_mltrain_loss_matches_scores_path(impl):
     """forward_mltrain_loss (fused projection + NLL) == CrossEntropy over forward_mltrain scores."""
     from golden_util import Fixture, assert_close

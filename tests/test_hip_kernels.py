@@ -119,7 +119,8 @@ def _ref_lstm(x, lens, lstm, h0, c0, up, uph, upc):
 @pytest.mark.parametrize('T,B,I,H,ragged', [(7, 5, 24, 64, True), (9, 20, 33, 128, True), (6, 40, 16, 64, True),
                                             (12, 128, 64, 512, False), (10, 70, 48, 256, True),
                                             (5, 300, 16, 64, True), (4, 40, 32, 1024, True),
-                                            (3, 256, 16, 1024, False)])
+                                            (3, 256, 16, 1024, False),
+                                            (3, 700, 16, 512, True)])     # more rows than one sweep holds: chunked
 def test_lstm_layer_fwd_bwd(ops, T, B, I, H, ragged):
     g = torch.Generator().manual_seed(T * 1000 + B)
     lstm = nn.LSTM(I, H, 1)

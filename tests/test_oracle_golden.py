@@ -45,6 +45,11 @@ def test_adv_step(name):
     sc.run_adv_step(oracle, 'cpu', name, TOL_OUT, TOL_GRAD)
 
 
+@pytest.mark.parametrize('name', sc.GSTEP)
+def test_gstep_variants(name):
+    sc.run_gstep_variant(oracle, 'cpu', name, TOL_OUT, TOL_GRAD)
+
+
 def test_init_quirks():
     """Forget-gate bias fill covers indices H+1..2H-1 only (index H untouched), value 1.0 for the
     translator and 2.0 for the classifier; decoder_W ranges (char_translator.py:121-161,

@@ -19,13 +19,14 @@ from .gen_decode import SoftSamples, sample_embed
 
 
 class _Conv1dTM(Function):
-    """x [T,B,C] (time major), weight [F,C,K], bias [F], zero padding K//2 -> pre-activations [Tout,B,F]."""
+    """x [T,B,C] (time major), weight [F,C,K], bias [F], zero padding `pad` (default K//2) on both sides
+    -> pre-activations [Tout,B,F]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, pad=None):
         T, B, C = x.shape
         Fo, _, K = weight.shape
-        pad = K // 2
+        pad = K // 2 if pad is None else int(pad)
         Tout = T + 2 * pad - K + 1
         x2 = x.contiguous().view(T * B, C)
         wk = weight.permute(2, 0, 1).contiguous()              # [K][F][C]
@@ -58,7 +59,7 @@ class _Conv1dTM(Function):
                 dwk[k].copy_(ops.gemm_auto(ds, xs, transA=True))
         dw = dwk.permute(1, 2, 0).contiguous() if dwk is not None else None
         db = ops.colsum(d2) if ctx.needs_input_grad[2] else None
-        return (dx.view(T, B, C) if dx is not None else None), dw, db
+        return (dx.view(T, B, C) if dx is not None else None), dw, db, None
 
 
 class _LreluMaxTime(Function):
@@ -92,10 +93,11 @@ class _LreluMaxTime(Function):
 class _ConvParams(nn.Module):
     """Holds weight [F,C,K] / bias [F] under nn.Conv1d's parameter names."""
 
-    def __init__(self, cin, nfilt, K):
+    def __init__(self, cin, nfilt, K, padding=None):
         super().__init__()
         self.K = K
-        ref = nn.Conv1d(cin, nfilt, K, padding=K // 2)         # consumes the RNG exactly like the reference
+        self.padding = K // 2 if padding is None else padding
+        ref = nn.Conv1d(cin, nfilt, K, padding=self.padding)   # consumes the RNG exactly like the reference
         self.weight = nn.Parameter(ref.weight.detach().clone())
         self.bias = nn.Parameter(ref.bias.detach().clone())
 

@@ -18,45 +18,83 @@ class RecParams(nn.Module):
     (uniform +-1/sqrt(H), drawn in nn.LSTM's parameter order so that a given torch seed yields the
     same weights as the reference's nn.LSTM)."""
 
-    def __init__(self, input_size, hidden_size, num_layers):
+    def __init__(self, input_size, hidden_size, num_layers, bidirectional=False):
         super().__init__()
         self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.bidirectional = bool(bidirectional)
         stdv = 1.0 / math.sqrt(hidden_size) if hidden_size > 0 else 0
         for k in range(num_layers):
-            isz = input_size if k == 0 else hidden_size
-            for name, shape in (('weight_ih_l%d' % k, (4 * hidden_size, isz)),
-                                ('weight_hh_l%d' % k, (4 * hidden_size, hidden_size)),
-                                ('bias_ih_l%d' % k, (4 * hidden_size,)), ('bias_hh_l%d' % k, (4 * hidden_size,))):
-                p = nn.Parameter(torch.empty(*shape))
-                nn.init.uniform_(p, -stdv, stdv)
-                self.register_parameter(name, p)
+            isz = input_size if k == 0 else hidden_size * (2 if self.bidirectional else 1)
+            for sfx in (['', '_reverse'] if self.bidirectional else ['']):
+                for name, shape in (('weight_ih_l%d%s' % (k, sfx), (4 * hidden_size, isz)),
+                                    ('weight_hh_l%d%s' % (k, sfx), (4 * hidden_size, hidden_size)),
+                                    ('bias_ih_l%d%s' % (k, sfx), (4 * hidden_size,)),
+                                    ('bias_hh_l%d%s' % (k, sfx), (4 * hidden_size,))):
+                    p = nn.Parameter(torch.empty(*shape))
+                    nn.init.uniform_(p, -stdv, stdv)
+                    self.register_parameter(name, p)
 
-    def layer(self, k):
-        return (getattr(self, 'weight_ih_l%d' % k), getattr(self, 'weight_hh_l%d' % k),
-                getattr(self, 'bias_ih_l%d' % k), getattr(self, 'bias_hh_l%d' % k))
+    def layer(self, k, reverse=False):
+        sfx = '_reverse' if reverse else ''
+        return (getattr(self, 'weight_ih_l%d%s' % (k, sfx)), getattr(self, 'weight_hh_l%d%s' % (k, sfx)),
+                getattr(self, 'bias_ih_l%d%s' % (k, sfx)), getattr(self, 'bias_hh_l%d%s' % (k, sfx)))
 
 
-def build_rec(in_size, hsz, depth, residual):
+def build_rec(in_size, hsz, depth, residual, bidirectional=False):
     """nn.LSTM(in,H,L) or, with residual connections, a ModuleList of 1-layer LSTMs
     (char_translator.py:74-78, char_lstm.py:55-59): same state_dict keys."""
     if residual:
         sizes = [in_size] + [hsz] * (depth - 1)
-        return nn.ModuleList([RecParams(sizes[i], hsz, 1) for i in range(depth)])
-    return RecParams(in_size, hsz, depth)
+        return nn.ModuleList([RecParams(sizes[i], hsz, 1, bidirectional) for i in range(depth)])
+    return RecParams(in_size, hsz, depth, bidirectional)
 
 
-def rec_layer_params(rec, residual, i):
-    return rec[i].layer(0) if residual else rec.layer(i)
+def rec_layer_params(rec, residual, i, reverse=False):
+    return rec[i].layer(0, reverse) if residual else rec.layer(i, reverse)
 
 
-def fill_forget_bias(rec, residual, depth, hsz, value):
+def fill_forget_bias(rec, residual, depth, hsz, value, bidirectional=False):
     """Reference quirk kept: index range arange(H+1, 2H), index H untouched
     (char_translator.py:138-161, char_lstm.py:121-134)."""
     with torch.no_grad():
         for i in range(depth):
-            _, _, b_ih, b_hh = rec_layer_params(rec, residual, i)
-            b_ih[hsz + 1:2 * hsz] = value
-            b_hh[hsz + 1:2 * hsz] = value
+            for rev in ([False, True] if bidirectional else [False]):
+                _, _, b_ih, b_hh = rec_layer_params(rec, residual, i, rev)
+                b_ih[hsz + 1:2 * hsz] = value
+                b_hh[hsz + 1:2 * hsz] = value
+
+
+def reverse_time(x, lens, T):
+    """Per-row time reversal of the valid prefix of a padded time-major batch (row b: steps 0..len_b-1 are
+    flipped, the padding stays where it is).  Its own inverse.  lens None: every row has T steps."""
+    if lens is None:
+        return x.flip(0)
+    l = torch.as_tensor([int(v) for v in lens], device=x.device).view(1, -1)
+    t = torch.arange(T, device=x.device).view(-1, 1)
+    idx = torch.where(t < l, l - 1 - t, t)                                     # [T,B]
+    return x.gather(0, idx.unsqueeze(-1).expand(-1, -1, x.shape[2]))
+
+
+def run_stack_bidir(rec, x, lens, depth, h_prev=None):
+    """Bidirectional stacked LSTM (nn.LSTM(bidirectional=True), char_lstm.py:57-59): the reverse direction is
+    the same persistent forward sweep over the per-row time-reversed input.  Returns (out [T,B,2H],
+    (h [2L,B,H], c [2L,B,H])) with nn.LSTM's state order (layer 0 fwd, layer 0 reverse, layer 1 fwd, ...)."""
+    T = x.shape[0]
+    lens_dev = lens_to_device(lens, T, x.device)
+    cur, hs, cs = x, [], []
+    for i in range(depth):
+        outs = []
+        for d, rev in enumerate((False, True)):
+            w_ih, w_hh, b_ih, b_hh = rec.layer(i, rev)
+            h0 = h_prev[0][2 * i + d] if h_prev is not None else None
+            c0 = h_prev[1][2 * i + d] if h_prev is not None else None
+            inp = reverse_time(cur, lens, T) if rev else cur
+            out, hN, cN = ops.lstm_layer(inp, w_ih, w_hh, b_ih, b_hh, lens_dev, h0, c0)
+            outs.append(reverse_time(out, lens, T) if rev else out)
+            hs.append(hN)
+            cs.append(cN)
+        cur = torch.cat(outs, dim=-1)
+    return cur, (torch.stack(hs, 0), torch.stack(cs, 0))
 
 
 def lens_to_device(lens, T, device):

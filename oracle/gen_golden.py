@@ -362,6 +362,80 @@ def fx_charlstm(cl):
         save(name, p, **arrs)
 
 
+def fx_charlstm_heads(cl):
+    """CharLstm options off the default path: bidirectional LSTM (with the only pooling it type-checks with),
+    MLP head, CNN-over-hidden head, generic real/fake head, compression layer; generative multi-head LM mode."""
+    cases = (('clf_lstm_bidir_mp2', dict(bidir=True, maxpoolrnn=2)),
+             ('clf_lstm_mlp', dict(decoder_mlp=20)),
+             ('clf_lstm_cnnhead', dict(decoder_cnn=1, decoder_cnn_ks=[2, 3], decoder_cnn_nfilt=12, hidden_depth=1)),
+             ('clf_lstm_generic', dict(generic_classifier=True, maxpoolrnn=1)),
+             ('clf_lstm_compress', dict(compression_layer=8)))
+    for name, over in cases:
+        g = torch.Generator().manual_seed(43)
+        torch.manual_seed(15)
+        p = eval_params(**over)
+        m = cl.CharLstm(p)
+        if hasattr(m, 'generic_W'):
+            with torch.no_grad():
+                m.generic_W.mul_(0.02)       # init is +-sqrt(fan_in): keep the sigmoid off saturation
+        m.train()
+        T, B = 7, 5
+        inps, targs, lens = synth_batch(g, T, B, V0)
+        labels = torch.LongTensor([0, 1, 1, 0, 1])
+
+        def run(x, **kw):
+            out = m.forward_classify(x, lens=lens, **kw)
+            loss = nn.functional.cross_entropy(out[0], labels)
+            if len(out) == 3:
+                loss = loss + nn.functional.binary_cross_entropy(out[2].view(-1), labels.float())
+            loss.backward()
+            return out, loss
+
+        out, loss = run(targs)
+        arrs = dict(x=targs, lens=np.array(lens), labels=labels, logits=out[0], loss=loss)
+        if len(out) == 3:
+            arrs['generic'] = out[2]
+        else:
+            arrs['feat'] = out[1]
+        arrs.update(sd_np(m, 'sd.'))
+        arrs.update(grads_np(m, 'grad.'))
+        m.zero_grad()
+        soft = torch.softmax(torch.randn(T, B, V0 + 1, generator=g) * 3, dim=-1)
+        for b, L in enumerate(lens):
+            soft[L:, b] = 0
+        soft.requires_grad_(True)
+        out_s, loss_s = run(soft, adv_inp=True, drop=False)
+        arrs.update(dict(soft=soft.detach(), logits_soft=out_s[0], loss_soft=loss_s, dsoft=soft.grad))
+        arrs.update(grads_np(m, 'gradsoft.'))
+        save(name, p, **arrs)
+
+    # generative mode: one output layer per author
+    g = torch.Generator().manual_seed(44)
+    torch.manual_seed(16)
+    p = eval_params(mode='generative')
+    m = cl.CharLstm(p)
+    with torch.no_grad():
+        m.decoder_W.mul_(3.0)
+    m.train()
+    T, B = 7, 5
+    inps, targs, lens = synth_batch(g, T, B, V0)
+    heads = torch.LongTensor([0, 1, 1, 0, 1])
+    from torch.nn.utils.rnn import pack_padded_sequence as pps
+    scores, _ = m.forward(inps, lens, None, heads)
+    loss = nn.functional.cross_entropy(pps(scores, lens)[0], pps(targs, lens)[0])
+    loss.backward()
+    arrs = dict(inps=inps, targs=targs, lens=np.array(lens), heads=heads, scores=scores, loss=loss)
+    arrs.update(sd_np(m, 'sd.'))
+    arrs.update(grads_np(m, 'grad.'))
+    m.eval()
+    seq = inps[:5, :1].contiguous()
+    probs, _ = m.forward_eval(seq, None)
+    # CharLstm.forward_gen feeds a 2-D embedding to nn.LSTM (char_lstm.py:255-258), which torch >= 1.11 reads as
+    # an unbatched sequence and rejects together with the 3-D state: it cannot be run here, so it is not pinned
+    arrs.update(dict(seq=seq, eval_probs=probs))
+    save('lm_multihead', p, **arrs)
+
+
 def fx_charcnn(cc):
     for name, over in (('clf_cnn_234', dict(decoder_cnn_ks=[2, 3, 4])),
                        ('clf_cnn_43', dict(decoder_cnn_ks=[4, 3])),
@@ -538,12 +612,16 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['gstep']:
         fx_gstep_variants(ct, cl)
         sys.exit(0)
+    if sys.argv[1:] == ['heads']:
+        fx_charlstm_heads(cl)
+        sys.exit(0)
     fx_translator_options(ct)
     fx_gstep_variants(ct, cl)
     fx_gumbel(ct)
     fx_translator_mltrain(ct)
     fx_advers_gen(ct)
     fx_charlstm(cl)
+    fx_charlstm_heads(cl)
     fx_charcnn(cc)
     fx_adv_step(ct, cl, cc)
     fx_init(ct, cl)

@@ -10,9 +10,8 @@ Follows, function by function (citations are into /root/reference):
 Differences from the reference are limited to what a Python-3 / device-agnostic restatement
 needs: no ``.cuda()`` in constructors, tensors follow the parameters' device, and every random
 draw of the Gumbel sampler goes through an injectable ``NoiseSource`` so fixtures can pin it.
-Options outside SURVEY.md section 8 (bidirectional / compression / MLP / CNN-over-hidden classifier
-heads, generative LM heads, the adv_targ language-model input) raise NotImplementedError instead of
-being silently approximated.
+Options outside SURVEY.md section 8 (the adv_targ language-model input) raise NotImplementedError
+instead of being silently approximated.
 """
 import math
 
@@ -354,75 +353,194 @@ class CharTranslator(nn.Module):
 # LSTM attribution classifier (discriminator)
 # ----------------------------------------------------------------------------------------------
 class CharLstm(nn.Module):
+    """models/char_lstm.py:32-340.  Classifier mode (default linear head; optional MLP / CNN-over-hidden heads,
+    generic real/fake head, bidirectional LSTM, compression layer) and the generative multi-head LM mode."""
+
     def __init__(self, params):
         super().__init__()
-        _unsupported(params, ['bidir', 'compression_layer', 'decoder_mlp', 'decoder_cnn', 'generic_classifier'])
-        if params.get('mode', 'generative') != 'classifier':
-            raise NotImplementedError('oracle: only mode="classifier" is on the hot path')
         self.output_size = params.get('vocabulary_size', -1) + 1
         self.num_output_layers = params.get('num_output_layers', 1)
         self.num_rec_layers = params.get('hidden_depth', -1)
         self.emb_size = params.get('embedding_size', -1)
         self.hidden_size = params.get('hidden_size', -1)
         self.en_residual = params.get('en_residual_conn', 0)
+        self.bidir = bool(params.get('bidir', 0))
+        self.compression_layer = params.get('compression_layer', 0)
         self.max_pool_rnn = params.get('maxpoolrnn', 0)
-        self.encoder = nn.Embedding(self.output_size, self.emb_size, padding_idx=0)
-        self.enc_drop = nn.Dropout(p=params.get('drop_prob_encoder', 0.25))
-        self.rec_layers = _build_rec(self.emb_size, self.hidden_size, self.num_rec_layers, self.en_residual)
-        if self.max_pool_rnn == 3:
-            # reference quirk (char_lstm.py:65 vs :309): decoder_W is sized 2H but the feature is
-            # H + L*H wide, so the head only type-checks when L == 1.
-            decoder_size = self.hidden_size * 2
+        self.classifier = params.get('mode', 'generative') == 'classifier'
+        H, D = self.hidden_size, 1 + int(self.bidir)
+        if self.compression_layer:
+            # vocabulary -> a few learnt "classes" (rows L1-normalised) -> embedding (:47-49, :114-118)
+            self.compression_W = nn.Embedding(self.output_size, self.compression_layer)
+            self.encoder = nn.Embedding(self.compression_layer, self.emb_size)
         else:
-            decoder_size = self.hidden_size * (1 + int(self.max_pool_rnn == 1))
-        self.decoder_W = nn.Parameter(torch.zeros(decoder_size, self.num_output_layers))
-        self.decoder_b = nn.Parameter(torch.zeros(self.num_output_layers))
+            self.encoder = nn.Embedding(self.output_size, self.emb_size, padding_idx=0)
+        self.enc_drop = nn.Dropout(p=params.get('drop_prob_encoder', 0.25))
+        if self.en_residual:
+            sizes = [self.emb_size] + [H] * (self.num_rec_layers - 1)
+            self.rec_layers = nn.ModuleList([nn.LSTM(sizes[i], H, 1, bidirectional=self.bidir)
+                                             for i in range(self.num_rec_layers)])
+        else:
+            self.rec_layers = nn.LSTM(self.emb_size, H, self.num_rec_layers, bidirectional=self.bidir)
+        self.head_mlp = self.head_cnn = False
+        if self.classifier:
+            # reference quirk (:65 vs :309): with maxpoolrnn == 3 decoder_W is sized 2H although the feature is
+            # H + L*H wide, so that head only type-checks when L == 1
+            decoder_size = H * (1 + int(self.max_pool_rnn in (1, 3))) * D
+            if params.get('decoder_mlp', 0):
+                self.decoder_W_mlp = nn.Parameter(torch.zeros(decoder_size, params['decoder_mlp']))
+                self.decoder_b_mlp = nn.Parameter(torch.zeros(params['decoder_mlp']))
+                decoder_size = params['decoder_mlp']
+                self.head_mlp = True
+            elif params.get('decoder_cnn', 0):
+                self.cnn_ks = params['decoder_cnn_ks']
+                self.cnn_nfilt = params['decoder_cnn_nfilt']
+                self.decoder_cnn = nn.ModuleList([nn.Conv1d(H, self.cnn_nfilt, K, padding=K) for K in self.cnn_ks])
+                self.head_cnn = True
+                decoder_size = self.cnn_nfilt * len(self.cnn_ks)
+            self.decoder_W = nn.Parameter(torch.zeros(decoder_size, self.num_output_layers))
+            self.decoder_b = nn.Parameter(torch.zeros(self.num_output_layers))
+            if params.get('generic_classifier', False):
+                self.generic_W = nn.Parameter(torch.zeros(H * (1 + int(self.max_pool_rnn == 1)), 1))
+                self.generic_b = nn.Parameter(torch.zeros(1))
+        else:
+            # one [H, V] output layer per author (:86-88)
+            self.decoder_W = nn.Parameter(torch.zeros(self.num_output_layers, H, self.output_size))
+            self.decoder_b = nn.Parameter(torch.zeros(self.num_output_layers, self.output_size))
         self.dec_drop = nn.Dropout(p=params.get('drop_prob_decoder', 0.25))
         self.init_weights()
 
     def init_weights(self):
         a = math.sqrt(float(self.decoder_W.shape[0]))
         with torch.no_grad():
+            if hasattr(self, 'generic_W'):
+                self.generic_W.uniform_(-a, a)
+                self.generic_b.zero_()
+            if self.head_mlp:
+                n_in = math.sqrt(float(self.decoder_W_mlp.shape[0]))
+                self.decoder_W_mlp.uniform_(-1.73 / n_in, 1.73 / n_in)
+                self.decoder_b_mlp.zero_()
             self.decoder_W.uniform_(-1.73 / a, 1.73 / a)
             self.decoder_b.zero_()
-        if self.en_residual:
+            if self.compression_layer:
+                w = self.compression_W.weight
+                w.div_(w.abs().sum(dim=1, keepdim=True))
+        sfx = ['', '_reverse'] if self.bidir else ['']
+        with torch.no_grad():
             for i in range(self.num_rec_layers):
-                _fill_forget_bias(self.rec_layers[i], [0], self.hidden_size, 2.0)
-        else:
-            _fill_forget_bias(self.rec_layers, range(self.num_rec_layers), self.hidden_size, 2.0)
+                lstm, lid = (self.rec_layers[i], 0) if self.en_residual else (self.rec_layers, i)
+                for sx in sfx:
+                    for nm in ('bias_ih_l%d%s' % (lid, sx), 'bias_hh_l%d%s' % (lid, sx)):
+                        getattr(lstm, nm)[self.hidden_size + 1:2 * self.hidden_size] = 2.0
 
     def init_hidden(self, bsz):
         w = self.decoder_W
-        return (w.new_zeros(self.num_rec_layers, bsz, self.hidden_size),
-                w.new_zeros(self.num_rec_layers, bsz, self.hidden_size))
+        n = self.num_rec_layers * (1 + int(self.bidir))
+        return (w.new_zeros(n, bsz, self.hidden_size), w.new_zeros(n, bsz, self.hidden_size))
+
+    def _rec(self, inp, h_prev):
+        return _run_rec(self.rec_layers, inp, h_prev, self.en_residual, self.num_rec_layers)
+
+    # -- generative multi-head language model (:166-261) ---------------------------------------
+    def forward(self, x, lengths, h_prev, target_head, compute_softmax=False):
+        dev = self.decoder_W.device
+        n_steps, b_sz = x.shape[0], x.shape[1]
+        emb = self.enc_drop(self.encoder(x.to(dev)))
+        rnn_out, hidden = self._rec(pack_padded_sequence(emb, lengths), h_prev)
+        rnn_out = self.dec_drop(pad_packed_sequence(rnn_out)[0])
+        n_t = rnn_out.shape[0]
+        head = target_head.to(dev)
+        W = self.decoder_W[head]                                    # [B, H, V]: each row's own output layer
+        b = self.decoder_b[head].view(b_sz, 1, self.output_size).expand(b_sz, n_t, self.output_size)
+        dec_out = torch.baddbmm(b, rnn_out.transpose(0, 1), W).transpose(0, 1)
+        if compute_softmax:
+            dec_out = F.softmax(dec_out.reshape(-1, self.output_size), dim=1).view(n_t, b_sz, self.output_size)
+        return dec_out, hidden
+
+    def forward_eval(self, x, h_prev, compute_softmax=True):
+        """One sequence ([T,1]) scored by every author's output layer -> [T, n_auth, V]."""
+        dev = self.decoder_W.device
+        n_auth, n_steps = self.num_output_layers, x.shape[0]
+        with torch.no_grad():
+            emb = self.encoder(x.to(dev))
+            rnn_out, hidden = self._rec(emb, h_prev)
+            rnn_out = rnn_out.expand(n_steps, n_auth, self.hidden_size)
+            b = self.decoder_b.view(n_auth, 1, self.output_size).expand(n_auth, n_steps, self.output_size)
+            dec_out = torch.baddbmm(b, rnn_out.transpose(0, 1), self.decoder_W).transpose(0, 1)
+            if compute_softmax:
+                dec_out = F.softmax(dec_out.reshape(-1, self.output_size), dim=1).view(n_steps, n_auth,
+                                                                                       self.output_size)
+        return dec_out, hidden
+
+    def forward_gen(self, x, h_prev, target_auth, n_max=100, end_c=-1):
+        """Greedy continuation of the seed x ([T,1]) with target_auth's output layer; never stops early (:252)."""
+        dev = self.decoder_W.device
+        with torch.no_grad():
+            rnn_out, hidden = self._rec(self.encoder(x.to(dev)), h_prev)
+            W = self.decoder_W[target_auth.to(dev)][0]
+            b = self.decoder_b[target_auth.to(dev)].view(1, self.output_size)
+            p_rnn = rnn_out[-1]
+            char_out = []
+            for _ in range(n_max):
+                pred_c = (p_rnn.mm(W) + b).argmax(dim=-1)
+                char_out.append(pred_c)
+                p_rnn, hidden = self._rec(self.encoder(pred_c).unsqueeze(0), hidden)
+                p_rnn = p_rnn[-1]
+        return char_out
+
+    # -- classifier (:263-340) -----------------------------------------------------------------
+    def _embed(self, x, adv_inp, dev):
+        n_steps, b_sz = x.shape[0], x.shape[1]
+        if self.compression_layer:
+            if not adv_inp:
+                comp = self.compression_W(x.to(dev)).view(n_steps * b_sz, -1)
+                qn = comp.abs().sum(dim=1, keepdim=True) + 1e-8
+            else:
+                comp = x.reshape(n_steps * b_sz, -1).mm(self.compression_W.weight)
+                qn = comp.abs().sum(dim=1, keepdim=True).detach() + 1e-8
+            return (comp / qn).mm(self.encoder.weight).view(n_steps, b_sz, -1)
+        if not adv_inp:
+            return self.encoder(x.to(dev))
+        return x.reshape(n_steps * b_sz, -1).mm(self.encoder.weight).view(n_steps, b_sz, -1)
 
     def forward_classify(self, x, h_prev=None, compute_softmax=False, predict_mode=False, adv_inp=False,
                          lens=None, drop=True):
         dev = self.decoder_W.device
-        n_steps, b_sz = x.shape[0], x.shape[1]
-        if not adv_inp:
-            emb = self.encoder(x.to(dev))
-        else:
-            emb = x.reshape(n_steps * b_sz, -1).mm(self.encoder.weight).view(n_steps, b_sz, -1)
-        if drop:
-            emb = self.enc_drop(emb)
-        packed = pack_padded_sequence(emb, lens)
-        rnn_out, hidden = _run_rec(self.rec_layers, packed, h_prev, self.en_residual, self.num_rec_layers)
-        if self.max_pool_rnn == 1:
-            ctxt = torch.cat([packed_mean(rnn_out), hidden[0][-1]], dim=-1)
-        elif self.max_pool_rnn == 2:
-            unp, _ = pad_packed_sequence(rnn_out)
-            ctxt = unp.max(dim=0)[0]
-        elif self.max_pool_rnn == 3:
-            unp, _ = pad_packed_sequence(rnn_out)
-            ctxt = torch.cat([unp.max(dim=0)[0], hidden[0].transpose(0, 1).contiguous().view(b_sz, -1)], dim=-1)
-        else:
-            ctxt = hidden[0][-1]
-        enc_out = self.dec_drop(ctxt) if drop else ctxt
-        dec_out = enc_out.mm(self.decoder_W) + self.decoder_b.view(1, -1)
-        if compute_softmax:
-            dec_out = F.softmax(dec_out, dim=-1)
-        return dec_out, enc_out
+        b_sz = x.shape[1]
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not predict_mode):
+            emb = self._embed(x, adv_inp, dev)
+            if drop:
+                emb = self.enc_drop(emb)
+            rnn_out, hidden = self._rec(pack_padded_sequence(emb, lens), h_prev)
+            if self.head_cnn:
+                # Conv1d(padding=K) over the (zero padded) hidden states, leaky_relu, max over time (:321-327);
+                # this dropout is applied whatever `drop` says
+                unp = pad_packed_sequence(rnn_out)[0].permute(1, 2, 0)
+                pooled = [F.leaky_relu(conv(unp)).max(dim=2)[0] for conv in self.decoder_cnn]
+                dec_in = self.dec_drop(torch.cat(pooled, dim=1))
+                enc_out = dec_in
+            else:
+                if self.max_pool_rnn == 1:
+                    ctxt = torch.cat([packed_mean(rnn_out), hidden[0][-1]], dim=-1)
+                elif self.max_pool_rnn == 2:
+                    ctxt = pad_packed_sequence(rnn_out)[0].max(dim=0)[0]
+                elif self.max_pool_rnn == 3:
+                    ctxt = torch.cat([pad_packed_sequence(rnn_out)[0].max(dim=0)[0],
+                                      hidden[0].transpose(0, 1).contiguous().view(b_sz, -1)], dim=-1)
+                else:
+                    ctxt = hidden[0][-1]
+                enc_out = self.dec_drop(ctxt) if drop else ctxt
+                dec_in = enc_out
+                if self.head_mlp:
+                    dec_in = torch.tanh(enc_out.mm(self.decoder_W_mlp) + self.decoder_b_mlp.view(1, -1))
+            dec_out = dec_in.mm(self.decoder_W) + self.decoder_b.view(1, -1)
+            if compute_softmax:
+                dec_out = F.softmax(dec_out, dim=-1)
+            if hasattr(self, 'generic_W'):
+                # real/fake head; note the reference returns the LSTM state, not the features, here (:335-338)
+                generic = torch.sigmoid(enc_out.mm(self.generic_W) + self.generic_b.view(1, 1))
+                return dec_out, hidden, generic
+            return dec_out, enc_out
 
 
 # ----------------------------------------------------------------------------------------------

@@ -51,6 +51,16 @@ def test_adv_step(impl, name):
     impl.check_timeouts()
 
 
+@pytest.mark.parametrize('name', sc.CLF_HEADS)
+def test_classifier_heads(impl, name):
+    sc.run_classifier_heads(impl, 'cuda', name, TOL_OUT, TOL_GRAD)
+    impl.check_timeouts()
+
+
+def test_lm_multihead(impl):
+    sc.run_lm_multihead(impl, 'cuda', TOL_OUT, TOL_GRAD)
+
+
 @pytest.mark.parametrize('name', sc.GSTEP)
 def test_gstep_variants(impl, name):
     sc.run_gstep_variant(impl, 'cuda', name, TOL_OUT, TOL_GRAD)

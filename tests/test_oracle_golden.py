@@ -45,6 +45,15 @@ def test_adv_step(name):
     sc.run_adv_step(oracle, 'cpu', name, TOL_OUT, TOL_GRAD)
 
 
+@pytest.mark.parametrize('name', sc.CLF_HEADS)
+def test_classifier_heads(name):
+    sc.run_classifier_heads(oracle, 'cpu', name, TOL_OUT, TOL_GRAD)
+
+
+def test_lm_multihead():
+    sc.run_lm_multihead(oracle, 'cpu', TOL_OUT, TOL_GRAD)
+
+
 @pytest.mark.parametrize('name', sc.GSTEP)
 def test_gstep_variants(name):
     sc.run_gstep_variant(oracle, 'cpu', name, TOL_OUT, TOL_GRAD)

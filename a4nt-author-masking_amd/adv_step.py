@@ -11,6 +11,8 @@ Differences from the reference driver are structural, not numerical:
   * the reconstruction loss uses the fused projection + NLL (forward_mltrain_loss);
   * gen_lens is read back once per generation (for the length sort), not once per step.
 """
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -95,6 +97,29 @@ def _sorted_encode(encoder, samples, lens_dev, start_id):
     enc_inp = samples.index_select_batch(sort_idx.to(dev)).prepend_token(start_id)
     rev_enc = encoder.forward_encode(enc_inp, len_sorted.tolist(), adv_inp=True)
     return rev_enc.index_select(0, rev_idx.to(dev))
+
+
+def gan_generator_loss(logits, targ_aid, wasserstein=False, maximize_entropy=0, sample_weight=None):
+    """The generator's GAN loss on the discriminator logits [B,C] (train_adversarial_translator.py:689-716):
+    5*BCE(fake, 1) [per-sample weights], the entropy (1, 2) / margin (3) variants, or -E_fake."""
+    gen_aid_out = logits[:, targ_aid]
+    if wasserstein:
+        return -gen_aid_out.mean()
+    if not maximize_entropy:
+        loss_aid = F.binary_cross_entropy_with_logits(gen_aid_out, torch.ones_like(gen_aid_out), weight=sample_weight)
+    elif maximize_entropy == 1:
+        p = torch.sigmoid(gen_aid_out)
+        loss_aid = 4. * (p * torch.log(p) + (1. - p) * torch.log(1. - p)).mean()
+    elif maximize_entropy == 2:
+        p = F.softmax(logits, dim=1)[:, targ_aid]
+        loss_aid = 4. * ((1. - p) * torch.log(1.2 * (1. - p))).mean()
+    else:
+        p = F.softmax(logits, dim=1)[:, targ_aid]
+        slp, b1, b2 = 0.7, 0.6, 0.7
+        pdet = p.detach()
+        loss_aid = (-torch.log(p) * (pdet < b1).float() + float(-math.log(b1)) * (pdet >= b1).float() +
+                    slp * (p - b2) * (pdet >= b2).float()).mean()
+    return 5 * loss_aid
 
 
 def _cycle_loss_fn(kind):
@@ -263,8 +288,13 @@ class GradAllReducer(object):
 
 
 def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c, maxlen, temp, step=True,
-             reducer=None, defer=False, gen=None):
+             reducer=None, defer=False, gen=None, wasserstein=False, fisher_gan=False, weight_penalty=0.0, alpha=None,
+             maximize_entropy=0):
     """One discriminator update (:433-547): BCE(real, 1) + BCE(fake, 0) on column 1 - c_aid, RMSprop, no clipping.
+    maximize_entropy != 0: two-class CE on both logits (:490-493).  wasserstein + fisher_gan: Fisher-GAN critic,
+    E_real - E_fake with the variance constraint and its multiplier `alpha` (1-element tensor with requires_grad,
+    updated in place, :498-514).  A discriminator with a compression layer adds the mean L1 norm of its
+    compression rows (:495-496).
 
     defer=True: return with the gradient exchange in flight and the optimizer step not yet applied;
     result['finish']() completes both.  g_update(before_disc=finish) calls it right before the
@@ -282,11 +312,32 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
     targ_aid = 1 - c_aid
     real_aid_out = eval_out_gt[0][:, targ_aid]
     gen_aid_out = outs[0][:, targ_aid]
-    loss = (F.binary_cross_entropy_with_logits(real_aid_out, torch.ones_like(real_aid_out)) +
-            F.binary_cross_entropy_with_logits(gen_aid_out, torch.zeros_like(gen_aid_out)))
+    extra = {}
     if reducer is not None:
         reducer.arm()
-    loss.backward()
+    if not wasserstein:
+        if maximize_entropy == 0:
+            loss = (F.binary_cross_entropy_with_logits(real_aid_out, torch.ones_like(real_aid_out)) +
+                    F.binary_cross_entropy_with_logits(gen_aid_out, torch.zeros_like(gen_aid_out)))
+        else:
+            n, dev = real_aid_out.shape[0], real_aid_out.device
+            loss = (F.cross_entropy(eval_out_gt[0], torch.full((n,), 1 - c_aid, dtype=torch.long, device=dev)) +
+                    F.cross_entropy(outs[0], torch.full((n,), 1 - targ_aid, dtype=torch.long, device=dev)))
+        if getattr(modelEval, 'compression_layer', 0):
+            loss = loss + modelEval.compression_W.weight.norm(p=1, dim=1).mean()
+        loss.backward()
+    else:
+        if not fisher_gan or alpha is None:
+            raise NotImplementedError('wasserstein needs fisher_gan and alpha (the reference\'s plain-WGAN branch '
+                                      'uses an undefined name, train_adversarial_translator.py:521)')
+        loss_aid = real_aid_out.mean() - gen_aid_out.mean()
+        constraint = 1 - (0.5 * (real_aid_out ** 2).mean() + 0.5 * (gen_aid_out ** 2).mean())
+        loss = (loss_aid + alpha * constraint - (weight_penalty / 2.) * (constraint ** 2)).sum()
+        (-loss).backward()                       # the critic ascends (backward(mone), :512)
+        with torch.no_grad():
+            alpha += weight_penalty * alpha.grad
+            alpha.grad.zero_()
+        extra = {'loss_aid': loss_aid.detach(), 'constraint': constraint.detach(), 'alpha': alpha.detach().clone()}
     if reducer is not None:
         reducer.launch()
 
@@ -298,6 +349,7 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
 
     res = {'loss': loss.detach(), 'fake_logits': outs[0].detach(), 'real_logits': eval_out_gt[0].detach(),
            'gen_lens': outs[3], 'char_outs': outs[4]}
+    res.update(extra)
     if defer:
         res['finish'] = finish
     else:
@@ -308,7 +360,7 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
 def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, append_symb, cycle_loss_type='ml',
              cycle_loss_w=1.0, grad_clip=10.0, step=True, reducer=None, before_disc=None, gen=None,
              modelGenEncoder=None, cycle_loss_func='l1', grad_filter=False, feature_matching=None, weigh_feat_match=0,
-             ml_update=0, tgt_batch=None):
+             ml_update=0, tgt_batch=None, wasserstein=False, maximize_entropy=0, weigh_difficult=0.):
     """One generator update (:553-735): 5*BCE(fake, 1) + cycle loss [+ feature matching], clip_grad_norm, RMSprop.
 
     cycle_loss_type: 'ml' (reconstruction CE through the teacher-forced pass), 'enc' (semantic encoder of the
@@ -316,6 +368,7 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
     the input vs. the time-summed reverse samples) or None.  modelGenEncoder: frozen CharTranslator(encoder_only=True)
     for the two encoder losses; cycle_loss_func 'l1' | 'cosine'.  feature_matching / ml_update use tgt_batch, a
     batch of the target author (:572-591).  grad_filter: the driver's GradFilter on both sample tensors.
+    GAN loss variants: wasserstein (-E_fake), maximize_entropy 1/2/3 and weigh_difficult (gan_generator_loss).
     before_disc: callable run after the generation forward and before the discriminator is used
     (the deferred tail of d_update)."""
     _set_requires_grad(modelEval, False)
@@ -342,6 +395,14 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
             ml_loss = ml_update * modelGen.forward_mltrain_loss(gt_inps, gt_lens, gt_inps, gt_lens, gt_targs,
                                                                 auths=gt_auths)
             ml_loss.backward()
+    sample_weight = None
+    if weigh_difficult > 0.:
+        if before_disc is not None:
+            before_disc()
+            before_disc = None
+        with torch.no_grad():
+            eval_out_inp = modelEval.forward_classify(targs, lens=lens, drop=False)
+        sample_weight = -F.log_softmax(eval_out_inp[0], dim=1)[:, 1 - c_aid]
     outs = adv_forward_pass(modelGen, modelEval, inps, lens, end_c=end_c, maxlen=maxlen, auths=auths,
                             cycle_compute=(cycle_loss_type is not None and cycle_loss_type != 'noncyc_enc'),
                             append_symb=append_symb, temp=temp, cycle_loss_type=cycle_loss_type, targs=targs,
@@ -380,7 +441,7 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
         raise NotImplementedError('cycle_loss_type %r' % (cycle_loss_type,))
     targ_aid = 1 - c_aid
     gen_aid_out = outs[0][:, targ_aid]
-    loss_gan = 5.0 * F.binary_cross_entropy_with_logits(gen_aid_out, torch.ones_like(gen_aid_out))
+    loss_gan = gan_generator_loss(outs[0], targ_aid, wasserstein, maximize_entropy, sample_weight)
     err = (gen_aid_out.detach() > 0.).float().mean()
     loss_tot = loss_gan + cyc_loss + fm_loss
     if reducer is not None:

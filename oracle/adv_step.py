@@ -16,6 +16,7 @@ fixtures are produced by running THIS glue over the REFERENCE's own model classe
 (oracle/gen_golden.py) and the tests run it over the oracle's and the HIP-backed classes.
 """
 import inspect
+import math
 
 import torch
 import torch.nn as nn
@@ -111,8 +112,14 @@ def _set_requires_grad(model, flag):
         p.requires_grad = flag
 
 
-def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c, maxlen, temp, step=True):
-    """One discriminator update (:433-547).  src_batch / tgt_batch = (inps, targs, auths, lens)."""
+def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c, maxlen, temp, step=True,
+             wasserstein=False, fisher_gan=False, weight_penalty=0.0, alpha=None, maximize_entropy=0):
+    """One discriminator update (:433-547).  src_batch / tgt_batch = (inps, targs, auths, lens).
+    Default: BCE(real, 1) + BCE(fake, 0) on the target author's logit.  maximize_entropy != 0: two-class CE on
+    both logits (:490-493).  wasserstein + fisher_gan: Fisher-GAN critic, E_real - E_fake with the variance
+    constraint and its Lagrange multiplier `alpha` (a 1-element tensor with requires_grad, updated in place,
+    :498-514; the reference's plain-WGAN branch references an undefined name, :521, and is not restated).
+    A discriminator with a compression layer adds the mean L1 norm of its rows (:495-496)."""
     _set_requires_grad(modelEval, True)
     _set_requires_grad(modelGen, False)
     inps, targs, auths, lens = src_batch
@@ -124,13 +131,59 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
     targ_aid = 1 - c_aid
     real_aid_out = eval_out_gt[0][:, targ_aid]
     gen_aid_out = outs[0][:, targ_aid]
-    bce = nn.BCEWithLogitsLoss()
-    loss = bce(real_aid_out, torch.ones_like(real_aid_out)) + bce(gen_aid_out, torch.zeros_like(gen_aid_out))
-    loss.backward()
+    extra = {}
+    if not wasserstein:
+        if maximize_entropy == 0:
+            bce = nn.BCEWithLogitsLoss()
+            loss = bce(real_aid_out, torch.ones_like(real_aid_out)) + bce(gen_aid_out, torch.zeros_like(gen_aid_out))
+        else:
+            n = real_aid_out.shape[0]
+            dev = real_aid_out.device
+            loss = (nn.functional.cross_entropy(eval_out_gt[0], torch.full((n,), 1 - c_aid, dtype=torch.long, device=dev)) +
+                    nn.functional.cross_entropy(outs[0], torch.full((n,), 1 - targ_aid, dtype=torch.long, device=dev)))
+        if getattr(modelEval, 'compression_layer', 0):
+            loss = loss + modelEval.compression_W.weight.norm(p=1, dim=1).mean()
+        loss.backward()
+    else:
+        assert fisher_gan and alpha is not None
+        loss_aid = real_aid_out.mean() - gen_aid_out.mean()
+        constraint = 1 - (0.5 * (real_aid_out ** 2).mean() + 0.5 * (gen_aid_out ** 2).mean())
+        loss_constraint = alpha * constraint - (weight_penalty / 2.) * (constraint ** 2)
+        loss = (loss_aid + loss_constraint).sum()
+        (-loss).backward()                       # the critic ascends (backward(mone), :512)
+        with torch.no_grad():
+            alpha += weight_penalty * alpha.grad
+            alpha.grad.zero_()
+        extra = {'loss_aid': loss_aid.detach(), 'constraint': constraint.detach(), 'alpha': alpha.detach().clone()}
     if step:
         optimEval.step()
-    return {'loss': loss.detach(), 'fake_logits': outs[0].detach(), 'real_logits': eval_out_gt[0].detach(),
-            'gen_lens': outs[3], 'char_outs': outs[4]}
+    res = {'loss': loss.detach(), 'fake_logits': outs[0].detach(), 'real_logits': eval_out_gt[0].detach(),
+           'gen_lens': outs[3], 'char_outs': outs[4]}
+    res.update(extra)
+    return res
+
+
+def gan_generator_loss(logits, targ_aid, wasserstein=False, maximize_entropy=0, sample_weight=None):
+    """train_adversarial_translator.py:689-716."""
+    gen_aid_out = logits[:, targ_aid]
+    if wasserstein:
+        return -gen_aid_out.mean()
+    if not maximize_entropy:
+        loss_aid = nn.functional.binary_cross_entropy_with_logits(gen_aid_out, torch.ones_like(gen_aid_out),
+                                                                  weight=sample_weight)
+    elif maximize_entropy == 1:
+        p = torch.sigmoid(gen_aid_out)
+        loss_aid = 4. * (p * torch.log(p) + (1. - p) * torch.log(1. - p)).mean()
+    elif maximize_entropy == 2:
+        p = nn.functional.softmax(logits, dim=1)[:, targ_aid]
+        loss_aid = 4. * ((1. - p) * torch.log(1.2 * (1. - p))).mean()
+    else:
+        p = nn.functional.softmax(logits, dim=1)[:, targ_aid]
+        slp, b1, b2 = 0.7, 0.6, 0.7
+        pdet = p.detach()
+        loss_aid = (-torch.log(p) * (pdet < b1).float() + float(-math.log(b1)) * (pdet >= b1).float() +
+                    slp * (p - b2) * (pdet >= b2).float()).mean()
+    return 5 * loss_aid
 
 
 def _cycle_loss_fn(kind):
@@ -144,8 +197,10 @@ def _cycle_loss_fn(kind):
 def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, append_symb,
              cycle_loss_type='ml', cycle_loss_w=1.0, grad_clip=10.0, step=True, modelGenEncoder=None,
              cycle_loss_func='l1', grad_filter=False, feature_matching=None, weigh_feat_match=0, ml_update=0,
-             tgt_batch=None):
-    """One generator update (:553-735).  tgt_batch: a batch of the target author (feature matching / ml_update)."""
+             tgt_batch=None, wasserstein=False, maximize_entropy=0, weigh_difficult=0.):
+    """One generator update (:553-735).  tgt_batch: a batch of the target author (feature matching / ml_update).
+    GAN loss: 5*BCE(fake, 1) (optionally weighted per sample by the discriminator's difficulty on the input,
+    :593-595, :693-694), one of the three entropy / margin variants (:697-710), or -E_fake (:712-716)."""
     _set_requires_grad(modelEval, False)
     _set_requires_grad(modelGen, True)
     optimGen.zero_grad()
@@ -168,6 +223,11 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
             ml_targ = pack_padded_sequence(gt_targs.to(ml_out.device), gt_lens)
             ml_loss = ml_update * nn.functional.cross_entropy(pack_padded_sequence(ml_out, gt_lens)[0], ml_targ[0])
             ml_loss.backward()
+    sample_weight = None
+    if weigh_difficult > 0.:
+        kw = {'drop': False} if _accepts_drop(modelEval) else {}
+        eval_out_inp = modelEval.forward_classify(targs, lens=lens, **kw)
+        sample_weight = (-nn.functional.log_softmax(eval_out_inp[0], dim=1)[:, 1 - c_aid]).detach()
     outs = adv_forward_pass(modelGen, modelEval, inps, lens, end_c=end_c, maxlen=maxlen, auths=auths,
                             cycle_compute=(cycle_loss_type is not None and cycle_loss_type != 'noncyc_enc'),
                             append_symb=append_symb, temp=temp, cycle_loss_type=cycle_loss_type, grad_filter=grad_filter)
@@ -214,7 +274,7 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
         raise NotImplementedError('oracle: cycle_loss_type %r' % cycle_loss_type)
     targ_aid = 1 - c_aid
     gen_aid_out = outs[0][:, targ_aid]
-    loss_gan = 5.0 * nn.functional.binary_cross_entropy_with_logits(gen_aid_out, torch.ones_like(gen_aid_out))
+    loss_gan = gan_generator_loss(outs[0], targ_aid, wasserstein, maximize_entropy, sample_weight)
     err = (gen_aid_out.detach() > 0.).float().mean()
     loss_tot = loss_gan + cyc_loss + fm_loss
     loss_tot.backward()

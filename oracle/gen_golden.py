@@ -594,6 +594,61 @@ def fx_gstep_variants(ct, cl):
         save(name, gp, **arrs)
 
 
+def fx_loss_variants(ct, cl):
+    """The driver's other GAN losses: Fisher-GAN critic update, two-class CE discriminator loss with a
+    compression-layer discriminator, Wasserstein / margin / difficulty-weighted generator losses."""
+    from oracle import adv_step
+    cases = (('dstep_fisher', 'd', dict(), dict(wasserstein=True, fisher_gan=True, weight_penalty=0.5)),
+             ('dstep_maxent_comp', 'd', dict(compression_layer=8), dict(maximize_entropy=1)),
+             ('gstep_wgan', 'g', dict(), dict(wasserstein=True)),
+             ('gstep_wd', 'g', dict(), dict(weigh_difficult=1.0)),
+             ('gstep_maxent3', 'g', dict(), dict(maximize_entropy=3)))
+    for name, which, ep_over, kw in cases:
+        g = torch.Generator().manual_seed(81)
+        torch.manual_seed(17)
+        gp = gen_params()
+        modelGen = ct.CharTranslator(gp)
+        scale_weights(modelGen, 300.0)
+        ep = eval_params(**ep_over)
+        modelEval = cl.CharLstm(ep)
+        modelGen.train()
+        modelEval.train()
+        optG, optE = adv_step.make_optimizers(modelGen, modelEval)
+        T, B = 7, 6
+        src = synth_batch(g, T, B, V0)
+        tgt = synth_batch(g, T, B, V0)
+        c_aid = 1
+        mk = lambda b, a: (b[0], b[1], torch.LongTensor([a] * B), b[2])
+        end_c, maxlen, temp = 1, T, 0.5
+        append = torch.zeros(1, B, V0 + 1)
+        append[:, :, 2] = 1.0
+        arrs = {}
+        arrs.update(sd_np(modelGen, 'sdG0.'))
+        arrs.update(sd_np(modelEval, 'sdE0.'))
+        noise = Noise(93)
+        ct.sample_gumbel = noise.sample_gumbel
+        if which == 'd':
+            kw2 = dict(kw)
+            if kw.get('fisher_gan'):
+                kw2['alpha'] = torch.full((1,), 0.3, requires_grad=True)
+            r = adv_step.d_update(modelGen, modelEval, optE, mk(src, c_aid), mk(tgt, 1 - c_aid), c_aid, end_c, maxlen,
+                                  temp, step=False, **kw2)
+            arrs.update(grads_np(modelEval, 'gradE.'))
+        else:
+            r = adv_step.g_update(modelGen, modelEval, optG, mk(src, c_aid), c_aid, end_c, maxlen, temp, append,
+                                  cycle_loss_type=None, grad_clip=10.0, step=False, **kw)
+            arrs.update(grads_np(modelGen, 'gradG.'))
+        for k, v in r.items():
+            arrs['r.' + k] = torch.stack(list(v), 0) if isinstance(v, list) else v
+        for nm, b in (('src', src), ('tgt', tgt)):
+            arrs[nm + '.inps'], arrs[nm + '.targs'], arrs[nm + '.lens'] = b[0], b[1], np.array(b[2])
+        for i, u in enumerate(noise.drawn):
+            arrs['u%d' % i] = u
+        arrs.update(dict(n_noise=len(noise.drawn), c_aid=c_aid, end_c=end_c, maxlen=maxlen, temp=temp, which=which,
+                         eval_params_json=np.array(json.dumps(ep)), step_kwargs_json=np.array(json.dumps(kw))))
+        save(name, gp, **arrs)
+
+
 def fx_init(ct, cl):
     torch.manual_seed(10)
     m = ct.CharTranslator(gen_params())
@@ -612,11 +667,15 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['gstep']:
         fx_gstep_variants(ct, cl)
         sys.exit(0)
+    if sys.argv[1:] == ['losses']:
+        fx_loss_variants(ct, cl)
+        sys.exit(0)
     if sys.argv[1:] == ['heads']:
         fx_charlstm_heads(cl)
         sys.exit(0)
     fx_translator_options(ct)
     fx_gstep_variants(ct, cl)
+    fx_loss_variants(ct, cl)
     fx_gumbel(ct)
     fx_translator_mltrain(ct)
     fx_advers_gen(ct)

@@ -16,6 +16,7 @@ CLF_LSTM = ['clf_lstm_mp0', 'clf_lstm_mp1', 'clf_lstm_mp2', 'clf_lstm_res']
 CLF_CNN = ['clf_cnn_234', 'clf_cnn_43', 'clf_cnn_3layer_res']
 ADV_STEP = ['adv_step_lstm', 'adv_step_cnn']
 CLF_HEADS = ['clf_lstm_bidir_mp2', 'clf_lstm_mlp', 'clf_lstm_cnnhead', 'clf_lstm_generic', 'clf_lstm_compress']
+LOSS_VARIANTS = ['dstep_fisher', 'dstep_maxent_comp', 'gstep_wgan', 'gstep_wd', 'gstep_maxent3']
 GSTEP = ['gstep_noncyc', 'gstep_enc_cos_gf', 'gstep_bow_fm_ml']
 
 
@@ -284,3 +285,39 @@ def run_lm_multihead(impl, device, tol_out, tol_grad):
         p, _ = m.forward_eval(seq, None, compute_softmax=False)
         assert int(c.view(-1)[0]) == int(p[-1, 1].argmax())
         seq = torch.cat([seq, c.view(1, 1).cpu()], 0)
+
+
+def run_loss_variant(impl, device, name, tol_out, tol_grad, step_mod=None):
+    """One discriminator or generator update with the driver's other GAN losses (Fisher-GAN critic, two-class
+    CE + compression regulariser, Wasserstein / margin / difficulty-weighted generator loss)."""
+    fx = Fixture(name)
+    step_mod = step_mod or impl
+    kw = fx.json('step_kwargs_json')
+    ep = fx.json('eval_params_json')
+    G = _load(impl.CharTranslator(fx.params), fx.group('sdG0.'), device).train()
+    E = _load(impl.CharLstm(ep), fx.group('sdE0.'), device).train()
+    optG, optE = step_mod.make_optimizers(G, E)
+    G.set_noise(fx.noise_list(device))
+    B = fx.t('src.inps').shape[1]
+    c_aid = int(fx.scalar('c_aid'))
+    end_c, maxlen, temp = int(fx.scalar('end_c')), int(fx.scalar('maxlen')), float(fx.scalar('temp'))
+    mk = lambda nm, a: (fx.t(nm + '.inps'), fx.t(nm + '.targs'), torch.LongTensor([a] * B), fx.np(nm + '.lens').tolist())
+    if str(fx.np('which')) == 'd':
+        if kw.get('fisher_gan'):
+            kw['alpha'] = torch.full((1,), 0.3, device=device, requires_grad=True)
+        r = step_mod.d_update(G, E, optE, mk('src', c_aid), mk('tgt', 1 - c_aid), c_aid, end_c, maxlen, temp,
+                              step=False, **kw)
+        assert_close(r['loss'], fx.t('r.loss'), tol_out, name + ' loss')
+        for k in ('loss_aid', 'constraint', 'alpha'):
+            if 'r.' + k in fx:
+                assert_close(r[k], fx.t('r.' + k), tol_out, name + ' ' + k)
+        assert_grads_close(E.named_parameters(), fx.group('gradE.'), tol_grad, name + ' D')
+    else:
+        append = torch.zeros(1, B, fx.params['vocabulary_size'] + 1, device=device)
+        append[:, :, 2] = 1.0
+        r = step_mod.g_update(G, E, optG, mk('src', c_aid), c_aid, end_c, maxlen, temp, append, cycle_loss_type=None,
+                              grad_clip=10.0, step=False, **kw)
+        assert torch.equal(torch.stack(list(r['char_outs']), 0).cpu().long(), fx.t('r.char_outs').long())
+        assert_close(r['loss_gan'], fx.t('r.loss_gan'), tol_out, name + ' gan loss')
+        assert_close(r['grad_norm'], fx.t('r.grad_norm'), tol_grad, name + ' grad norm')
+        assert_grads_close(G.named_parameters(), fx.group('gradG.'), tol_grad, name + ' G')

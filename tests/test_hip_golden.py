@@ -61,6 +61,12 @@ def test_lm_multihead(impl):
     sc.run_lm_multihead(impl, 'cuda', TOL_OUT, TOL_GRAD)
 
 
+@pytest.mark.parametrize('name', sc.LOSS_VARIANTS)
+def test_loss_variants(impl, name):
+    sc.run_loss_variant(impl, 'cuda', name, TOL_OUT, TOL_GRAD)
+    impl.check_timeouts()
+
+
 @pytest.mark.parametrize('name', sc.GSTEP)
 def test_gstep_variants(impl, name):
     sc.run_gstep_variant(impl, 'cuda', name, TOL_OUT, TOL_GRAD)

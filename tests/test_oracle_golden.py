@@ -54,6 +54,11 @@ def test_lm_multihead():
     sc.run_lm_multihead(oracle, 'cpu', TOL_OUT, TOL_GRAD)
 
 
+@pytest.mark.parametrize('name', sc.LOSS_VARIANTS)
+def test_loss_variants(name):
+    sc.run_loss_variant(oracle, 'cpu', name, TOL_OUT, TOL_GRAD)
+
+
 @pytest.mark.parametrize('name', sc.GSTEP)
 def test_gstep_variants(name):
     sc.run_gstep_variant(oracle, 'cpu', name, TOL_OUT, TOL_GRAD)

@@ -16,6 +16,8 @@ from .char_cnn import CharCNN                                             # noqa
 from .model_utils import get_classifier                                   # noqa: F401
 from .adv_step import (adv_forward_pass, d_update, g_update, fused_update, make_optimizers,    # noqa: F401
                        GradAllReducer, synthetic_batch)
+from .data_provider import DataProvider                                   # noqa: F401
+from . import eval_utils                                                  # noqa: F401
 from .ops import check_timeouts, lstm_set_max_workgroups                  # noqa: F401
 
 load_library()

@@ -112,6 +112,33 @@ def eval_translator(dp, model, params, char_to_ix, auth_to_ix, split='val', max_
     return cur_loss, float(np.exp(cur_loss))
 
 
+def eval_forward_pass(modelGen, modelEval, inps, lens, end_c=0, maxlen=100, auths=None, cycle_compute=True,
+                      append_symb=None):
+    """The translation pass of the evaluation driver (eval_gantranslate.py:19-53): greedy translation to `auths`,
+    classifier probabilities of the translated ids, and the greedy reverse translation of those ids.
+    append_symb: [1,1] LongTensor holding the start id.  Returns (probs [B,C] in input order, char_outs, gen_lens
+    [, rev_char_outs, rev_gen_lens])."""
+    modelGen.eval()
+    modelEval.eval()
+    b_sz = len(lens)
+    with torch.no_grad():
+        _, gen_lens, char_outs = modelGen.forward_advers_gen(inps, lens, end_c=end_c, n_max=maxlen, auths=auths,
+                                                             soft_samples=False)
+        len_sorted, sort_idx = gen_lens.cpu().sort(dim=0, descending=True, stable=True)
+        _, rev_sort_idx = sort_idx.sort(dim=0)
+        eval_inp = torch.stack(list(char_outs), 0).cpu().index_select(1, sort_idx)
+        probs = modelEval.forward_classify(eval_inp, lens=len_sorted.tolist(), compute_softmax=True)[0]
+        probs = probs.detach().index_select(0, rev_sort_idx.to(probs.device))
+        if not cycle_compute:
+            return probs, char_outs, gen_lens
+        reverse_inp = torch.cat([append_symb.cpu().repeat(1, b_sz), eval_inp], dim=0)
+        _, rev_lens, rev_chars = modelGen.forward_advers_gen(reverse_inp, len_sorted.tolist(), end_c=end_c,
+                                                             n_max=maxlen, auths=1 - auths, soft_samples=False)
+        rev_dev = rev_sort_idx.to(rev_lens.device)
+        rev_chars = [rc.index_select(0, rev_dev) for rc in rev_chars]
+    return probs, char_outs, gen_lens, rev_chars, rev_lens
+
+
 def make_checkpoint(it, params, eval_params, misc, modelGen, modelEval, optimGen, optimEval, val_loss=0., val_pplx=0.,
                     loss=0.):
     """The dictionary the GAN driver saves (train_adversarial_translator.py:791-802); torch.save it."""

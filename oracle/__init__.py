@@ -14,4 +14,5 @@ restatement against them.
 """
 from .models import (NoiseSource, CharTranslator, CharLstm, CharCNN, get_classifier,  # noqa: F401
                      gumbel_softmax_sample, sample_gumbel)
-from .adv_step import adv_forward_pass, d_update, g_update, AdvState, make_optimizers  # noqa: F401
+from .adv_step import (adv_forward_pass, d_update, g_update, AdvState, make_optimizers,  # noqa: F401
+                       eval_forward_pass)

@@ -87,6 +87,31 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
     return (eval_out_unsorted,) + tuple(eval_out_gen[1:]) + samples_out
 
 
+def eval_forward_pass(modelGen, modelEval, inps, lens, end_c=0, maxlen=100, auths=None, cycle_compute=True,
+                      append_symb=None):
+    """The translation pass of the evaluation driver (eval_gantranslate.py:19-53): greedy translation to
+    `auths`, classifier probabilities of the translated ids, and the greedy reverse translation of those ids.
+    append_symb: [1,1] LongTensor holding the start id."""
+    modelGen.eval()
+    modelEval.eval()
+    b_sz = len(lens)
+    with torch.no_grad():
+        _, gen_lens, char_outs = modelGen.forward_advers_gen(inps, lens, end_c=end_c, n_max=maxlen, auths=auths,
+                                                             soft_samples=False)
+        len_sorted, sort_idx = gen_lens.sort(dim=0, descending=True)
+        _, rev_sort_idx = sort_idx.sort(dim=0)
+        eval_inp = torch.stack(list(char_outs), 0).index_select(1, sort_idx)
+        probs = modelEval.forward_classify(eval_inp, lens=len_sorted.tolist(), compute_softmax=True)[0]
+        probs = probs.detach().index_select(0, rev_sort_idx)
+        if not cycle_compute:
+            return probs, char_outs, gen_lens
+        reverse_inp = torch.cat([append_symb.to(eval_inp.device).repeat(1, b_sz), eval_inp], dim=0)
+        _, rev_lens, rev_chars = modelGen.forward_advers_gen(reverse_inp, len_sorted.tolist(), end_c=end_c,
+                                                             n_max=maxlen, auths=1 - auths, soft_samples=False)
+        rev_chars = [rc.index_select(0, rev_sort_idx) for rc in rev_chars]
+    return probs, char_outs, gen_lens, rev_chars, rev_lens
+
+
 class AdvState(object):
     """Scalars the reference loop carries between iterations (:351-382)."""
 

@@ -649,6 +649,35 @@ def fx_loss_variants(ct, cl):
         save(name, gp, **arrs)
 
 
+def fx_eval_translate(ct, cl):
+    """Evaluation-time translation pass (eval_gantranslate.py:19-53): greedy translation, classifier
+    probabilities on the translated ids, greedy reverse translation."""
+    from oracle import adv_step
+    g = torch.Generator().manual_seed(95)
+    torch.manual_seed(18)
+    gp = gen_params()
+    modelGen = ct.CharTranslator(gp)
+    scale_weights(modelGen, 300.0)
+    ep = eval_params()
+    modelEval = cl.CharLstm(ep)
+    T, B = 7, 5
+    inps, targs, lens = synth_batch(g, T, B, V0)
+    auths = torch.LongTensor([1] * B)
+    append = torch.LongTensor([[2]])
+    modelGen.eval()
+    with torch.no_grad():
+        _, _, co = modelGen.forward_advers_gen(inps, lens, soft_samples=False, n_max=9, end_c=-1, auths=auths)
+    end_c = int(co[3][2])
+    out = adv_step.eval_forward_pass(modelGen, modelEval, inps, lens, end_c=end_c, maxlen=9, auths=auths,
+                                     cycle_compute=True, append_symb=append)
+    arrs = dict(inps=inps, lens=np.array(lens), auths=auths, end_c=end_c, maxlen=9, probs=out[0],
+                char_outs=torch.stack(list(out[1]), 0), gen_lens=out[2], rev_char_outs=torch.stack(list(out[3]), 0),
+                rev_gen_lens=out[4], eval_params_json=np.array(json.dumps(ep)))
+    arrs.update(sd_np(modelGen, 'sdG.'))
+    arrs.update(sd_np(modelEval, 'sdE.'))
+    save('eval_translate', gp, **arrs)
+
+
 def fx_init(ct, cl):
     torch.manual_seed(10)
     m = ct.CharTranslator(gen_params())
@@ -667,6 +696,9 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['gstep']:
         fx_gstep_variants(ct, cl)
         sys.exit(0)
+    if sys.argv[1:] == ['evaltr']:
+        fx_eval_translate(ct, cl)
+        sys.exit(0)
     if sys.argv[1:] == ['losses']:
         fx_loss_variants(ct, cl)
         sys.exit(0)
@@ -676,6 +708,7 @@ if __name__ == '__main__':
     fx_translator_options(ct)
     fx_gstep_variants(ct, cl)
     fx_loss_variants(ct, cl)
+    fx_eval_translate(ct, cl)
     fx_gumbel(ct)
     fx_translator_mltrain(ct)
     fx_advers_gen(ct)

@@ -321,3 +321,19 @@ def run_loss_variant(impl, device, name, tol_out, tol_grad, step_mod=None):
         assert_close(r['loss_gan'], fx.t('r.loss_gan'), tol_out, name + ' gan loss')
         assert_close(r['grad_norm'], fx.t('r.grad_norm'), tol_grad, name + ' grad norm')
         assert_grads_close(G.named_parameters(), fx.group('gradG.'), tol_grad, name + ' G')
+
+
+def run_eval_translate(impl, device, fwd, tol_out):
+    """Evaluation-time translation pass: greedy tokens, lengths and reverse translation exact, classifier
+    probabilities within tolerance.  fwd: the eval_forward_pass restatement under test."""
+    fx = Fixture('eval_translate')
+    ep = fx.json('eval_params_json')
+    G = _load(impl.CharTranslator(fx.params), fx.group('sdG.'), device)
+    E = _load(impl.CharLstm(ep), fx.group('sdE.'), device)
+    out = fwd(G, E, fx.t('inps'), fx.np('lens').tolist(), end_c=int(fx.scalar('end_c')), maxlen=int(fx.scalar('maxlen')),
+              auths=fx.t('auths'), cycle_compute=True, append_symb=torch.LongTensor([[2]]))
+    assert torch.equal(torch.stack(list(out[1]), 0).cpu().long(), fx.t('char_outs').long())
+    assert torch.equal(out[2].cpu().long(), fx.t('gen_lens').long())
+    assert torch.equal(torch.stack(list(out[3]), 0).cpu().long(), fx.t('rev_char_outs').long())
+    assert torch.equal(out[4].cpu().long(), fx.t('rev_gen_lens').long())
+    assert_close(out[0], fx.t('probs'), tol_out, 'eval_translate classifier probabilities')

@@ -73,6 +73,11 @@ def test_gstep_variants(impl, name):
     impl.check_timeouts()
 
 
+def test_eval_translate(impl):
+    sc.run_eval_translate(impl, 'cuda', impl.eval_utils.eval_forward_pass, TOL_OUT)
+    impl.check_timeouts()
+
+
 def test_mltrain_loss_matches_scores_path(impl):
     """forward_mltrain_loss (fused projection + NLL) == CrossEntropy over forward_mltrain scores."""
     from golden_util import Fixture, assert_close

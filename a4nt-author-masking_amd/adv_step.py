@@ -122,6 +122,22 @@ def gan_generator_loss(logits, targ_aid, wasserstein=False, maximize_entropy=0, 
     return 5 * loss_aid
 
 
+def _language_model_ce(lang_model, lang_map, samples, lens_dev, start_id):
+    """CE of the language model's next-symbol scores against the generated sentence itself (:669-678)."""
+    gl = lens_dev.cpu()
+    len_sorted, sort_idx = gl.sort(dim=0, descending=True, stable=True)
+    dev = samples.val.device
+    enc_inp = samples.index_select_batch(sort_idx.to(dev)).prepend_token(start_id)
+    from .gen_decode import mapped
+    ll = len_sorted.tolist()
+    lm_inp = mapped(enc_inp, lang_map)                   # rows = one_hot(tok) * val @ lang_map, never materialised
+    # target of position t = arg max of the mapped row t+1 (:677); val > 0, so that is the map row's arg max
+    targ_ids = lang_map.argmax(dim=1)[enc_inp.tok[1:]]
+    lang_prob, _ = lang_model.forward_mltrain(lm_inp, ll, lm_inp, ll, adv_targ=True)
+    tp = torch.nn.utils.rnn.pack_padded_sequence(targ_ids, ll)
+    return F.cross_entropy(torch.nn.utils.rnn.pack_padded_sequence(lang_prob, ll)[0], tp[0])
+
+
 def _cycle_loss_fn(kind):
     """train_adversarial_translator.py:324: CosineEmbeddingLoss(margin=0.1) against ones, or L1."""
     if kind == 'cosine':
@@ -360,7 +376,8 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
 def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, append_symb, cycle_loss_type='ml',
              cycle_loss_w=1.0, grad_clip=10.0, step=True, reducer=None, before_disc=None, gen=None,
              modelGenEncoder=None, cycle_loss_func='l1', grad_filter=False, feature_matching=None, weigh_feat_match=0,
-             ml_update=0, tgt_batch=None, wasserstein=False, maximize_entropy=0, weigh_difficult=0.):
+             ml_update=0, tgt_batch=None, wasserstein=False, maximize_entropy=0, weigh_difficult=0., language_loss=0.,
+             lang_model=None, lang_map=None):
     """One generator update (:553-735): 5*BCE(fake, 1) + cycle loss [+ feature matching], clip_grad_norm, RMSprop.
 
     cycle_loss_type: 'ml' (reconstruction CE through the teacher-forced pass), 'enc' (semantic encoder of the
@@ -369,6 +386,9 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
     for the two encoder losses; cycle_loss_func 'l1' | 'cosine'.  feature_matching / ml_update use tgt_batch, a
     batch of the target author (:572-591).  grad_filter: the driver's GradFilter on both sample tensors.
     GAN loss variants: wasserstein (-E_fake), maximize_entropy 1/2/3 and weigh_difficult (gan_generator_loss).
+    language_loss: weight of the CE of a frozen decoder-only language model `lang_model` on the generated
+    sentence (:668-683); lang_map [V, V_lm] maps this vocabulary onto the language model's (the samples stay
+    compact: the language model embeds them with lang_map @ its embedding matrix).
     before_disc: callable run after the generation forward and before the discriminator is used
     (the deferred tail of d_update)."""
     _set_requires_grad(modelEval, False)
@@ -439,11 +459,16 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
         cyc_loss = torch.zeros((), device=dev)
     else:
         raise NotImplementedError('cycle_loss_type %r' % (cycle_loss_type,))
+    lang_loss = torch.zeros((), device=dev)
+    if language_loss:
+        lang_loss = language_loss * _language_model_ce(lang_model, lang_map, outs[2], outs[3], _start_id(append_symb))
+        if float(lang_loss.detach()) > 20:               # the reference drops an exploding language loss (:679-681)
+            lang_loss = torch.zeros((), device=dev)
     targ_aid = 1 - c_aid
     gen_aid_out = outs[0][:, targ_aid]
     loss_gan = gan_generator_loss(outs[0], targ_aid, wasserstein, maximize_entropy, sample_weight)
     err = (gen_aid_out.detach() > 0.).float().mean()
-    loss_tot = loss_gan + cyc_loss + fm_loss
+    loss_tot = loss_gan + cyc_loss + fm_loss + lang_loss
     if reducer is not None:
         reducer.arm()
     loss_tot.backward()
@@ -454,7 +479,7 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
     if step:
         optimGen.step()
     res = {'loss': loss_tot.detach(), 'loss_gan': loss_gan.detach(), 'cyc_loss': cyc_loss.detach(),
-           'fm_loss': fm_loss.detach(), 'grad_norm': gnorm.detach(), 'err': err, 'gen_lens': outs[3],
+           'fm_loss': fm_loss.detach(), 'lang_loss': lang_loss.detach(), 'grad_norm': gnorm.detach(), 'err': err, 'gen_lens': outs[3],
            'char_outs': outs[4], 'fake_logits': outs[0].detach()}
     if ml_loss is not None:
         res['ml_loss'] = ml_loss.detach()

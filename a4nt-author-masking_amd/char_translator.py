@@ -151,7 +151,7 @@ class CharTranslator(nn.Module):
         return out, hidden
 
     # -- teacher forced (char_translator.py:200-286) -------------------------------------------
-    def _mltrain_hidden(self, inp, lengths_inp, targ, lengths_targ, h_prev, auths, adv_inp, sort_enc):
+    def _mltrain_hidden(self, inp, lengths_inp, targ, lengths_targ, h_prev, auths, adv_inp, sort_enc, adv_targ=False):
         dev = self._dev()
         soft = adv_inp or isinstance(inp, SoftSamples)
         T_in, B = inp.shape[0], inp.shape[1]
@@ -178,8 +178,17 @@ class CharTranslator(nn.Module):
             raise ops.A4NTError('no_encoder with pad_auth_vec > 0: the decoder input would be narrower than its '
                                 'weights (the reference fails the same way, char_translator.py:86,260)')
 
-        targ = targ.to(dev)
-        targ_emb = self._drop(ops.embedding(targ, self.char_emb.weight, 0), self.p_emb)
+        if adv_targ or isinstance(targ, SoftSamples):
+            # soft target rows (the language-model loss feeds generated samples, char_translator.py:252-254)
+            if isinstance(targ, SoftSamples):
+                t_emb = sample_embed(targ, self.char_emb.weight)
+            else:
+                t_emb = ops.linear_kn(targ.reshape(targ.shape[0] * targ.shape[1], -1), self.char_emb.weight).view(
+                    targ.shape[0], targ.shape[1], -1)
+            targ_emb = self._drop(t_emb, self.p_emb)
+        else:
+            targ = targ.to(dev)
+            targ_emb = self._drop(ops.embedding(targ, self.char_emb.weight, 0), self.p_emb)
         n_t = targ.shape[0]
         lens_dev = lens_to_device(lengths_targ, n_t, dev)
         dec_rec, W_out, b_out = self._decoder(auths)
@@ -197,10 +206,8 @@ class CharTranslator(nn.Module):
 
     def forward_mltrain(self, inp, lengths_inp, targ, lengths_targ, h_prev=None, compute_softmax=False, auths=None,
                         adv_inp=False, sort_enc=None, adv_targ=False):
-        if adv_targ:
-            raise NotImplementedError('adv_targ (language-model loss) is outside the hot-path scope')
         dec_out, n_t, B, hidden, W_out, b_out = self._mltrain_hidden(inp, lengths_inp, targ, lengths_targ, h_prev, auths,
-                                                                     adv_inp, sort_enc)
+                                                                     adv_inp, sort_enc, adv_targ)
         score = ops.linear_kn(dec_out.reshape(n_t * B, -1), W_out, b_out)
         if compute_softmax:
             score = F.log_softmax(score, dim=1)

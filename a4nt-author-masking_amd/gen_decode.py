@@ -42,9 +42,12 @@ class SoftSamples(object):
     from generator step t - t_offset, generator batch column perm[b].
     """
 
-    def __init__(self, tok, val, vocab, origin=None, const_rows=0):
+    def __init__(self, tok, val, vocab, origin=None, const_rows=0, vocab_map=None):
         self.tok, self.val, self.vocab, self.origin = tok, val, vocab, origin
         self.const_rows = const_rows      # leading rows that are constant one-hot rows (prepend_token)
+        # [V, V'] matrix applied to every row before a consumer sees it (samples.mm(vocab_map), the vocabulary
+        # map of the language-model loss): consumers embed with vocab_map @ W, tokens stay in this vocabulary
+        self.vocab_map = vocab_map
 
     @property
     def shape(self):
@@ -132,7 +135,15 @@ class _SampleEmbed(Function):
 
 
 def sample_embed(samples, W):
+    if samples.vocab_map is not None:
+        W = ops.linear_kn(samples.vocab_map, W)
     return _SampleEmbed.apply(samples.val, samples.tok, W, samples.origin)
+
+
+def mapped(samples, vocab_map):
+    """samples.mm(vocab_map) for every row, kept compact."""
+    assert samples.vocab_map is None
+    return SoftSamples(samples.tok, samples.val, vocab_map.shape[1], samples.origin, samples.const_rows, vocab_map)
 
 
 class _DenseFromCompact(Function):

@@ -222,7 +222,8 @@ def _cycle_loss_fn(kind):
 def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, append_symb,
              cycle_loss_type='ml', cycle_loss_w=1.0, grad_clip=10.0, step=True, modelGenEncoder=None,
              cycle_loss_func='l1', grad_filter=False, feature_matching=None, weigh_feat_match=0, ml_update=0,
-             tgt_batch=None, wasserstein=False, maximize_entropy=0, weigh_difficult=0.):
+             tgt_batch=None, wasserstein=False, maximize_entropy=0, weigh_difficult=0., language_loss=0.,
+             lang_model=None, lang_map=None):
     """One generator update (:553-735).  tgt_batch: a batch of the target author (feature matching / ml_update).
     GAN loss: 5*BCE(fake, 1) (optionally weighted per sample by the discriminator's difficulty on the input,
     :593-595, :693-694), one of the three entropy / margin variants (:697-710), or -E_fake (:712-716)."""
@@ -297,17 +298,32 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
         cyc_loss = torch.zeros((), device=dev)
     else:
         raise NotImplementedError('oracle: cycle_loss_type %r' % cycle_loss_type)
+    lang_loss = torch.zeros((), device=dev)
+    if language_loss:
+        # a frozen decoder-only language model of the target author scores the generated sentence (:668-683);
+        # lang_map [V, V_lm] maps this vocabulary onto the language model's
+        gen_samples, gen_lens = outs[2], outs[3]
+        len_sorted, sort_idx = gen_lens.sort(dim=0, descending=True)
+        enc_inp = torch.cat([append_symb, gen_samples.index_select(1, sort_idx)])
+        n_steps, b_sz = enc_inp.shape[0], enc_inp.shape[1]
+        lm_inp = enc_inp.view(n_steps * b_sz, -1).mm(lang_map).view(n_steps, b_sz, -1)
+        ll = len_sorted.tolist()
+        lang_prob, _ = lang_model.forward_mltrain(lm_inp, ll, lm_inp, ll, adv_targ=True)
+        lm_targ = pack_padded_sequence(lm_inp.detach()[1:].max(dim=-1)[1], ll)
+        lang_loss = language_loss * nn.functional.cross_entropy(pack_padded_sequence(lang_prob, ll)[0], lm_targ[0])
+        if float(lang_loss.detach()) > 20:
+            lang_loss = torch.zeros((), device=dev)
     targ_aid = 1 - c_aid
     gen_aid_out = outs[0][:, targ_aid]
     loss_gan = gan_generator_loss(outs[0], targ_aid, wasserstein, maximize_entropy, sample_weight)
     err = (gen_aid_out.detach() > 0.).float().mean()
-    loss_tot = loss_gan + cyc_loss + fm_loss
+    loss_tot = loss_gan + cyc_loss + fm_loss + lang_loss
     loss_tot.backward()
     gnorm = torch.nn.utils.clip_grad_norm_(modelGen.parameters(), grad_clip)
     if step:
         optimGen.step()
     res = {'loss': loss_tot.detach(), 'loss_gan': loss_gan.detach(), 'cyc_loss': cyc_loss.detach(),
-           'fm_loss': fm_loss.detach(), 'grad_norm': gnorm.detach() if torch.is_tensor(gnorm) else torch.tensor(gnorm),
+           'fm_loss': fm_loss.detach(), 'lang_loss': lang_loss.detach(), 'grad_norm': gnorm.detach() if torch.is_tensor(gnorm) else torch.tensor(gnorm),
            'err': err, 'gen_lens': outs[3], 'char_outs': outs[4], 'fake_logits': outs[0].detach()}
     if ml_loss is not None:
         res['ml_loss'] = ml_loss.detach()

@@ -649,6 +649,74 @@ def fx_loss_variants(ct, cl):
         save(name, gp, **arrs)
 
 
+def fx_language_loss(ct, cl):
+    """adv_targ (soft target rows into a decoder-only translator) and the generator update's language-model loss."""
+    from oracle import adv_step
+    from torch.nn.utils.rnn import pack_padded_sequence as pps
+    # (1) forward_mltrain(adv_targ=True) on a decoder-only model
+    g = torch.Generator().manual_seed(97)
+    torch.manual_seed(19)
+    V_lm = 30
+    lp = gen_params(no_encoder=1, pad_auth_vec=0, vocabulary_size=V_lm)
+    lm = ct.CharTranslator(lp)
+    scale_weights(lm, 100.0)
+    lm.train()
+    T, B = 7, 5
+    lens = [7, 6, 6, 4, 3]
+    soft = torch.softmax(torch.randn(T, B, V_lm + 1, generator=g) * 3, dim=-1)
+    soft.requires_grad_(True)
+    scores, _ = lm.forward_mltrain(soft, lens, soft, lens, adv_targ=True)
+    targ_ids = torch.randint(1, V_lm + 1, (T, B), generator=g)
+    loss = nn.functional.cross_entropy(pps(scores, lens)[0], pps(targ_ids, lens)[0])
+    loss.backward()
+    arrs = dict(soft=soft.detach(), lens=np.array(lens), targ_ids=targ_ids, scores=scores, loss=loss, dsoft=soft.grad)
+    arrs.update(sd_np(lm, 'sd.'))
+    arrs.update(grads_np(lm, 'grad.'))
+    save('mltrain_advtarg_noenc', lp, **arrs)
+
+    # (2) generator update with the language-model loss (vocabulary map: every id i -> i % (V_lm+1))
+    g = torch.Generator().manual_seed(98)
+    torch.manual_seed(20)
+    gp = gen_params()
+    modelGen = ct.CharTranslator(gp)
+    scale_weights(modelGen, 300.0)
+    ep = eval_params()
+    modelEval = cl.CharLstm(ep)
+    lm = ct.CharTranslator(lp)
+    scale_weights(lm, 100.0)
+    lm.train()
+    for p_ in lm.parameters():
+        p_.requires_grad = False
+    lang_map = torch.zeros(V0 + 1, V_lm + 1)
+    lang_map[torch.arange(V0 + 1), torch.arange(V0 + 1) % (V_lm + 1)] = 1.
+    modelGen.train()
+    modelEval.train()
+    optG, optE = adv_step.make_optimizers(modelGen, modelEval)
+    T, B = 7, 6
+    gb = synth_batch(g, T, B, V0)
+    c_aid = 0
+    mk = lambda b, a: (b[0], b[1], torch.LongTensor([a] * B), b[2])
+    append = torch.zeros(1, B, V0 + 1)
+    append[:, :, 2] = 1.0
+    arrs = {}
+    arrs.update(sd_np(modelGen, 'sdG0.'))
+    arrs.update(sd_np(modelEval, 'sdE0.'))
+    arrs.update(sd_np(lm, 'sdLM.'))
+    noise = Noise(99)
+    ct.sample_gumbel = noise.sample_gumbel
+    rg = adv_step.g_update(modelGen, modelEval, optG, mk(gb, c_aid), c_aid, 1, T, 0.5, append, cycle_loss_type=None,
+                           grad_clip=10.0, step=False, language_loss=0.8, lang_model=lm, lang_map=lang_map)
+    arrs.update(grads_np(modelGen, 'gradG.'))
+    for k, v in rg.items():
+        arrs['g.' + k] = torch.stack(list(v), 0) if isinstance(v, list) else v
+    arrs['gb.inps'], arrs['gb.targs'], arrs['gb.lens'] = gb[0], gb[1], np.array(gb[2])
+    for i, u in enumerate(noise.drawn):
+        arrs['u%d' % i] = u
+    arrs.update(dict(n_noise=len(noise.drawn), c_aid=c_aid, end_c=1, maxlen=T, temp=0.5, lang_map=lang_map,
+                     eval_params_json=np.array(json.dumps(ep)), lm_params_json=np.array(json.dumps(lp))))
+    save('gstep_langloss', gp, **arrs)
+
+
 def fx_eval_translate(ct, cl):
     """Evaluation-time translation pass (eval_gantranslate.py:19-53): greedy translation, classifier
     probabilities on the translated ids, greedy reverse translation."""
@@ -696,6 +764,9 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['gstep']:
         fx_gstep_variants(ct, cl)
         sys.exit(0)
+    if sys.argv[1:] == ['lang']:
+        fx_language_loss(ct, cl)
+        sys.exit(0)
     if sys.argv[1:] == ['evaltr']:
         fx_eval_translate(ct, cl)
         sys.exit(0)
@@ -709,6 +780,7 @@ if __name__ == '__main__':
     fx_gstep_variants(ct, cl)
     fx_loss_variants(ct, cl)
     fx_eval_translate(ct, cl)
+    fx_language_loss(ct, cl)
     fx_gumbel(ct)
     fx_translator_mltrain(ct)
     fx_advers_gen(ct)

@@ -10,8 +10,7 @@ Follows, function by function (citations are into /root/reference):
 Differences from the reference are limited to what a Python-3 / device-agnostic restatement
 needs: no ``.cuda()`` in constructors, tensors follow the parameters' device, and every random
 draw of the Gumbel sampler goes through an injectable ``NoiseSource`` so fixtures can pin it.
-Options outside SURVEY.md section 8 (the adv_targ language-model input) raise NotImplementedError
-instead of being silently approximated.
+Every constructor option and method of the four model files is restated.
 """
 import math
 
@@ -239,8 +238,6 @@ class CharTranslator(nn.Module):
     # -- teacher forced (char_translator.py:200-286) -------------------------------------------
     def forward_mltrain(self, inp, lengths_inp, targ, lengths_targ, h_prev=None, compute_softmax=False,
                         auths=None, adv_inp=False, sort_enc=None, adv_targ=False):
-        if adv_targ:
-            raise NotImplementedError('oracle: adv_targ (language-model loss) is out of scope')
         dev = self._dev()
         b_sz = inp.shape[1]
         enc_hidden = None
@@ -266,8 +263,12 @@ class CharTranslator(nn.Module):
             else:
                 ctxt = self.enc_drop(ctxt)
 
-        targ = targ.to(dev)
-        targ_emb = self.emb_drop(self.char_emb(targ))
+        if not adv_targ:
+            targ = targ.to(dev)
+            targ_emb = self.emb_drop(self.char_emb(targ))
+        else:
+            # soft target rows (the language-model loss feeds generated samples, char_translator.py:252-254)
+            targ_emb = self.emb_drop(self._soft_embed(targ))
         n_t = targ.shape[0]
         if not self.no_encoder:
             dec_inp = torch.cat([ctxt.unsqueeze(0).expand(n_t, b_sz, ctxt.shape[1]), targ_emb], dim=-1)

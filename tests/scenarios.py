@@ -337,3 +337,48 @@ def run_eval_translate(impl, device, fwd, tol_out):
     assert torch.equal(torch.stack(list(out[3]), 0).cpu().long(), fx.t('rev_char_outs').long())
     assert torch.equal(out[4].cpu().long(), fx.t('rev_gen_lens').long())
     assert_close(out[0], fx.t('probs'), tol_out, 'eval_translate classifier probabilities')
+
+
+def run_mltrain_advtarg(impl, device, tol_out, tol_grad):
+    """forward_mltrain(adv_targ=True): soft rows as the decoder's input on a decoder-only translator."""
+    name = 'mltrain_advtarg_noenc'
+    fx = Fixture(name)
+    m = _load(impl.CharTranslator(fx.params), fx.group('sd.'), device).train()
+    lens = fx.np('lens').tolist()
+    soft = fx.t('soft', device).requires_grad_(True)
+    scores, _ = m.forward_mltrain(soft, lens, soft, lens, adv_targ=True)
+    loss = _packed_ce(scores, fx.t('targ_ids'), lens)
+    loss.backward()
+    assert_close(scores, fx.t('scores'), tol_out, name + ' scores')
+    assert_close(loss, fx.t('loss'), tol_out, name + ' loss')
+    assert_close(soft.grad, fx.t('dsoft'), tol_grad, name + ' dsoft')
+    assert_grads_close(m.named_parameters(), fx.group('grad.'), tol_grad, name)
+
+
+def run_gstep_langloss(impl, device, tol_out, tol_grad, step_mod=None):
+    """Generator update with the language-model loss (train_adversarial_translator.py:668-683)."""
+    name = 'gstep_langloss'
+    fx = Fixture(name)
+    step_mod = step_mod or impl
+    ep = fx.json('eval_params_json')
+    G = _load(impl.CharTranslator(fx.params), fx.group('sdG0.'), device).train()
+    E = _load(impl.CharLstm(ep), fx.group('sdE0.'), device).train()
+    LM = _load(impl.CharTranslator(fx.json('lm_params_json')), fx.group('sdLM.'), device).train()
+    for p in LM.parameters():
+        p.requires_grad = False
+    optG, _ = step_mod.make_optimizers(G, E)
+    G.set_noise(fx.noise_list(device))
+    B = fx.t('gb.inps').shape[1]
+    c_aid = int(fx.scalar('c_aid'))
+    batch = (fx.t('gb.inps'), fx.t('gb.targs'), torch.LongTensor([c_aid] * B), fx.np('gb.lens').tolist())
+    append = torch.zeros(1, B, fx.params['vocabulary_size'] + 1, device=device)
+    append[:, :, 2] = 1.0
+    rg = step_mod.g_update(G, E, optG, batch, c_aid, int(fx.scalar('end_c')), int(fx.scalar('maxlen')),
+                           float(fx.scalar('temp')), append, cycle_loss_type=None, grad_clip=10.0, step=False,
+                           language_loss=0.8, lang_model=LM, lang_map=fx.t('lang_map', device))
+    assert torch.equal(torch.stack(list(rg['char_outs']), 0).cpu().long(), fx.t('g.char_outs').long())
+    assert float(fx.t('g.lang_loss')) > 0
+    assert_close(rg['lang_loss'], fx.t('g.lang_loss'), tol_out, name + ' language loss')
+    assert_close(rg['loss_gan'], fx.t('g.loss_gan'), tol_out, name + ' gan loss')
+    assert_close(rg['grad_norm'], fx.t('g.grad_norm'), tol_grad, name + ' grad norm')
+    assert_grads_close(G.named_parameters(), fx.group('gradG.'), tol_grad, name + ' G')

@@ -73,6 +73,15 @@ def test_gstep_variants(impl, name):
     impl.check_timeouts()
 
 
+def test_mltrain_advtarg(impl):
+    sc.run_mltrain_advtarg(impl, 'cuda', TOL_OUT, TOL_GRAD)
+
+
+def test_gstep_langloss(impl):
+    sc.run_gstep_langloss(impl, 'cuda', TOL_OUT, TOL_GRAD)
+    impl.check_timeouts()
+
+
 def test_eval_translate(impl):
     sc.run_eval_translate(impl, 'cuda', impl.eval_utils.eval_forward_pass, TOL_OUT)
     impl.check_timeouts()

@@ -64,6 +64,14 @@ def test_gstep_variants(name):
     sc.run_gstep_variant(oracle, 'cpu', name, TOL_OUT, TOL_GRAD)
 
 
+def test_mltrain_advtarg():
+    sc.run_mltrain_advtarg(oracle, 'cpu', TOL_OUT, TOL_GRAD)
+
+
+def test_gstep_langloss():
+    sc.run_gstep_langloss(oracle, 'cpu', TOL_OUT, TOL_GRAD)
+
+
 def test_eval_translate():
     sc.run_eval_translate(oracle, 'cpu', oracle.eval_forward_pass, TOL_OUT)
 

@@ -18,6 +18,9 @@ _SIGS = {
     'a4nt_sgemm': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int,
                            c_longlong, P]),
     'a4nt_sgemm_tile': (c_int, [c_int, c_int, c_int]),
+    'a4nt_sgemm_set_kgroups': (c_int, [c_int]),
+    'a4nt_sgemm_nt_rows_ok': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'a4nt_sgemm_nt_rows': (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'a4nt_sgemm_skinny_ksplit': (c_int, [c_int, c_int, c_int]),
     'a4nt_sgemm_skinny': (c_int, [c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_longlong, P]),
     'a4nt_lstm_geometry': (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),

@@ -36,7 +36,7 @@ struct StageKC {
     // EDGE=true : only kleft < BK columns are valid (last, partial K tile): per-element dword loads
     template <bool EDGE>
     __device__ __forceinline__ void load(const float* base, int ld, int r0, int rmax, int k0, int kmax) {
-        const int tid = threadIdx.x;
+        const int tid = threadIdx.x & 255;      // 256 staging threads per k-group
         const int kq = (tid % KQ) * 4;
         const int nrows = min(ROWS, rmax - r0);
         const int kleft = kmax - k0;
@@ -61,7 +61,7 @@ struct StageKC {
         }
     }
     __device__ __forceinline__ void store(float* S /* [BKT][ROWS+LPAD] */) const {
-        const int tid = threadIdx.x;
+        const int tid = threadIdx.x & 255;      // 256 staging threads per k-group
         const int kq = (tid % KQ) * 4;
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
@@ -83,7 +83,7 @@ struct StageMC {
     // EDGE=false: all COLS columns valid; EDGE=true: only cleft < COLS columns (last tile column / row block)
     template <bool EDGE>
     __device__ __forceinline__ void load(const float* base, int ld, int c0, int cmax, int k0, int kmax) {
-        const int tid = threadIdx.x;
+        const int tid = threadIdx.x & 255;      // 256 staging threads per k-group
         const int nk = min(BKT, kmax - k0);
         const int cleft = cmax - c0;
         const float* origin = base + (long long)k0 * ld + c0;
@@ -109,7 +109,7 @@ struct StageMC {
         }
     }
     __device__ __forceinline__ void store(float* S /* [BK][COLS+LPAD] */) const {
-        const int tid = threadIdx.x;
+        const int tid = threadIdx.x & 255;      // 256 staging threads per k-group
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int idx = tid + 256 * p;

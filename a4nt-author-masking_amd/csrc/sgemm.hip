@@ -10,6 +10,10 @@
 // Arbitrary M, N, K and leading dimensions: rows that are not 16-byte aligned (V = 10001) fall back
 // to dword loads, everything is bounds-checked.  Split-K writes per-slice slabs (deterministic;
 // the consumer sums them).
+// Few-tile products (the per-step decode GEMMs: 128 rows) run 64x64 tiles with KG "k-groups" of 4 waves
+// per workgroup: every group walks its own part of the workgroup's K range through its own LDS buffers
+// and the groups' accumulators are summed through LDS at the end.  That puts 2-4 waves on each SIMD of
+// a CU that holds one tile (the single-group kernel was latency bound there) without more C slabs.
 #include "common.h"
 
 #define BK 16
@@ -57,15 +61,18 @@ __device__ __forceinline__ void mma_tile(const float* as, const float* bs, int l
 // K loop.  EA / EB: the "mn contiguous" operand of this workgroup is an edge tile (dword loads).
 // Full K tiles run through a PF-deep register ring with branch-free loads (tiles past the end load
 // zeros); a partial last K tile is staged synchronously afterwards.
+// [kbeg, kend) is this k-group's range (possibly empty); nk and partial are workgroup-uniform: the loop
+// trip count (the largest group's full tiles) and whether some group has a partial last tile -- every
+// group runs the same barriers, a group with less work multiplies zeros.
 template <bool TA, bool TB, int WM, int WN, int PF, bool EA, bool EB>
-__device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kbeg, int kend, float (*As)[BK * (64 * WM + LPAD)],
+__device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kbeg, int kend, int nk, bool partial,
+                                       float (*As)[BK * (64 * WM + LPAD)],
                                        float (*Bs)[BK * (64 * WN + LPAD)], int lane, int wm, int wn,
                                        f32x16 (&acc)[WM][WN]) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     typename StageSel<TA, BM>::type sa[PF];      // TA: A stored [K][M] -> mn contiguous
     typename StageSel<!TB, BN>::type sb[PF];     // !TB: B stored [K][N] -> mn contiguous
-    const int nk = (kend - kbeg) / BK;           // full tiles
-    const int kfull = kbeg + nk * BK;            // ring loads see [kbeg, kfull): anything later reads as zeros
+    const int kfull = kbeg + max(0, (kend - kbeg) / BK) * BK;   // ring loads see [kbeg, kfull): anything later reads as zeros
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         sa[u].template load<TA && EA>(g.A, g.lda, m0, g.M, kbeg + u * BK, kfull);
@@ -91,7 +98,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kb
             __syncthreads();
         }
     }
-    if (kfull < kend) {                                 // partial last K tile
+    if (partial) {                                      // partial last K tile (zeros for the groups without one)
         sa[0].template load<true>(g.A, g.lda, m0, g.M, kfull, kend);
         sb[0].template load<true>(g.B, g.ldb, n0, g.N, kfull, kend);
         sa[0].store(As[0]);
@@ -101,20 +108,31 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kb
     }
 }
 
-template <bool TA, bool TB, int WM, int WN, int PF>
-__global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
+template <bool TA, bool TB, int WM, int WN, int PF, int KG>
+__global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    __shared__ __attribute__((aligned(16))) float As[2][BK * (BM + LPAD)];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * (BN + LPAD)];
+    constexpr int ASZ = BK * (BM + LPAD), BSZ = BK * (BN + LPAD);
+    static_assert(KG == 1 || (WM == 1 && WN == 1), "k-groups: 64x64 tiles only");
+    __shared__ __attribute__((aligned(16))) float smem[KG * 2 * (ASZ + BSZ)];
+    const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;   // wave-uniform: descriptors stay in SGPRs
+    float (*As)[ASZ] = reinterpret_cast<float (*)[ASZ]>(smem + grp * 2 * (ASZ + BSZ));
+    float (*Bs)[BSZ] = reinterpret_cast<float (*)[BSZ]>(smem + grp * 2 * (ASZ + BSZ) + 2 * ASZ);
 
     const int tile = blockIdx.x;
     const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
-    const int kend = min(g.K, kbeg + g.kchunk);
+    const int wg_kbeg = blockIdx.z * g.kchunk;
+    const int wg_kend = min(g.K, wg_kbeg + g.kchunk);
+    // k-groups: ceil(tiles/KG) K tiles each
+    const int wg_len = max(0, wg_kend - wg_kbeg);
+    const int tg = ((wg_len + BK - 1) / BK + KG - 1) / KG;
+    const int kbeg = wg_kbeg + grp * tg * BK;
+    const int kend = min(wg_kend, kbeg + tg * BK);
+    const int nk = min(tg, wg_len / BK);               // group 0 has the most full tiles
+    const bool partial = (wg_len % BK) != 0;
     float* C = g.C + (long long)blockIdx.z * g.slab;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
 
     f32x16 acc[WM][WN];
@@ -128,10 +146,25 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
     // workgroup-uniform edge flags of the "mn contiguous" operands (K-contiguous ones need none)
     const bool ea = TA && (g.M - m0 < BM);
     const bool eb = !TB && (g.N - n0 < BN);
-    if (!ea && !eb) k_loop<TA, TB, WM, WN, PF, false, false>(g, m0, n0, kbeg, kend, As, Bs, lane, wm, wn, acc);
-    else if (ea && !eb) k_loop<TA, TB, WM, WN, PF, true, false>(g, m0, n0, kbeg, kend, As, Bs, lane, wm, wn, acc);
-    else if (!ea && eb) k_loop<TA, TB, WM, WN, PF, false, true>(g, m0, n0, kbeg, kend, As, Bs, lane, wm, wn, acc);
-    else k_loop<TA, TB, WM, WN, PF, true, true>(g, m0, n0, kbeg, kend, As, Bs, lane, wm, wn, acc);
+    if (!ea && !eb) k_loop<TA, TB, WM, WN, PF, false, false>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc);
+    else if (ea && !eb) k_loop<TA, TB, WM, WN, PF, true, false>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc);
+    else if (!ea && eb) k_loop<TA, TB, WM, WN, PF, false, true>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc);
+    else k_loop<TA, TB, WM, WN, PF, true, true>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc);
+
+    if (KG > 1) {                                      // sum the k-groups' accumulators into group 0
+        __syncthreads();                               // every group is done with its staging buffers
+        float* red = smem;                             // [KG-1][4 waves][16][64]
+        if (grp > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((grp - 1) * 4 + wave) * 16 + r) * 64 + lane] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int q = 0; q < KG - 1; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[((q * 4 + wave) * 16 + r) * 64 + lane];
+    }
 
     // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const bool add_bias = (g.bias != nullptr) && (blockIdx.z == 0);
@@ -155,13 +188,13 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
         }
 }
 
-template <bool TA, bool TB, int WM, int WN, int PF>
+template <bool TA, bool TB, int WM, int WN, int PF, int KG = 1>
 static int launch_sgemm(GemmArgs g, int ksplit, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     dim3 grid(tiles_m * g.tiles_n, 1, ksplit);
-    hipLaunchKernelGGL((sgemm_kernel<TA, TB, WM, WN, PF>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((sgemm_kernel<TA, TB, WM, WN, PF, KG>), grid, dim3(256 * KG), 0, s, g);
     return a4nt_check_launch("sgemm");
 }
 
@@ -170,6 +203,36 @@ static int launch_sgemm(GemmArgs g, int ksplit, hipStream_t s) {
 extern "C" int a4nt_sgemm_tile(int M, int N, int ksplit) {
     const long long big_tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * (ksplit < 1 ? 1 : ksplit);
     return big_tiles >= 200 ? 128 : 64;
+}
+
+// k-groups of a 64x64-tile launch: two once the launch is small enough to leave most CUs with one tile
+// (measured: 28 -> 23 us for the [128 x 10001] x [10001 x 512] split-K product of a decoder step; four
+// groups were never better), while each group keeps at least 4 K tiles.  a4nt_sgemm_set_kgroups(n > 0) pins it (benchmarks), 0 = this rule.
+static int g_kgroups = 0;
+extern "C" int a4nt_sgemm_set_kgroups(int n) {
+    if (n != 0 && n != 1 && n != 2 && n != 4) {
+        a4nt_set_error("a4nt_sgemm_set_kgroups: %d (0 = automatic, 1, 2 or 4)", n);
+        return A4NT_ERR_ARG;
+    }
+    g_kgroups = n;
+    return A4NT_OK;
+}
+static int small_kgroups(int M, int N, int kchunk, int ksplit) {
+    if (g_kgroups) return g_kgroups;
+    const long long wgs = (long long)((M + 63) / 64) * ((N + 63) / 64) * ksplit;
+    const int ktiles = (kchunk + BK - 1) / BK;
+    int kg = wgs <= 768 ? 2 : 1;
+    while (kg > 1 && ktiles / kg < 4) kg >>= 1;
+    return kg;
+}
+
+template <bool TA, bool TB>
+static int launch_small(GemmArgs g, int ksplit, hipStream_t s) {
+    switch (small_kgroups(g.M, g.N, g.kchunk, ksplit)) {
+        case 4: return launch_sgemm<TA, TB, 1, 1, PFS, 4>(g, ksplit, s);
+        case 2: return launch_sgemm<TA, TB, 1, 1, PFS, 2>(g, ksplit, s);
+        default: return launch_sgemm<TA, TB, 1, 1, PFS, 1>(g, ksplit, s);
+    }
 }
 
 extern "C" int a4nt_sgemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
@@ -195,7 +258,7 @@ extern "C" int a4nt_sgemm(int transA, int transB, int M, int N, int K, const flo
     g.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
     const bool big = a4nt_sgemm_tile(M, N, ksplit) == 128;
-    if (!transA && !transB) return big ? launch_sgemm<false, false, 2, 2, PFB>(g, ksplit, s) : launch_sgemm<false, false, 1, 1, PFS>(g, ksplit, s);
-    if (!transA && transB) return big ? launch_sgemm<false, true, 2, 2, PFB>(g, ksplit, s) : launch_sgemm<false, true, 1, 1, PFS>(g, ksplit, s);
-    return big ? launch_sgemm<true, false, 2, 2, PFB>(g, ksplit, s) : launch_sgemm<true, false, 1, 1, PFS>(g, ksplit, s);
+    if (!transA && !transB) return big ? launch_sgemm<false, false, 2, 2, PFB>(g, ksplit, s) : launch_small<false, false>(g, ksplit, s);
+    if (!transA && transB) return big ? launch_sgemm<false, true, 2, 2, PFB>(g, ksplit, s) : launch_small<false, true>(g, ksplit, s);
+    return big ? launch_sgemm<true, false, 2, 2, PFB>(g, ksplit, s) : launch_small<true, false>(g, ksplit, s);
 }

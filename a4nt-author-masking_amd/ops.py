@@ -69,6 +69,9 @@ def _ld(t):
     return max(int(t.stride(0)), int(t.shape[1])) if t.shape[0] > 1 else int(max(t.shape[1], 1))
 
 
+NT_ROWS = True      # route few-row NT products with K <= 512 to a4nt_sgemm_nt_rows (benchmarks switch it off)
+
+
 def gemm(A, B, transA=False, transB=False, bias=None, out=None, beta=0, ksplit=1):
     """out[M,N] (+)= op(A) op(B) (+ bias).  ksplit>1 returns the [ksplit,M,N] partial slabs."""
     lib = _lib.load()
@@ -99,12 +102,37 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, beta=0, ksplit=1
             check(lib.a4nt_sgemm_skinny(0, M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc, _p(bias), int(beta), 1, 0,
                                         _s()), 'a4nt_sgemm_skinny')
         return out
+    if (transB and not transA and ksplit == 1 and bias is None and 96 <= M <= 256 and N >= 4096 and NT_ROWS
+            and lib.a4nt_sgemm_nt_rows_ok(M, N, K, _ld(A), _ld(B)) and (A.data_ptr() | B.data_ptr()) % 16 == 0):
+        # few rows x [N,K] weight with K <= 512 (one decoder step's d(sample) += d(emb) E^T): A-stationary kernel
+        with _Timed('sgemm_nt_rows' if TIMER is not None else None, 2.0 * M * N * K):
+            check(lib.a4nt_sgemm_nt_rows(M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc, int(beta), _s()),
+                  'a4nt_sgemm_nt_rows')
+        return out
     label = None
     if TIMER is not None:
         label = 'sgemm_%s_%d' % ('tn' if transA else ('nt' if transB else 'nn'), lib.a4nt_sgemm_tile(M, N, int(ksplit)))
     with _Timed(label, 2.0 * M * N * K):
         check(lib.a4nt_sgemm(int(transA), int(transB), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc,
                              _p(bias), int(beta), int(ksplit), M * ldc if ksplit > 1 else 0, _s()), 'a4nt_sgemm')
+    return out
+
+
+def gemm_nt_rows(A, B, out=None, beta=0):
+    """out (+)= A @ B^T through a4nt_sgemm_nt_rows (few rows, K <= 512; raises when the shape does not qualify)."""
+    lib = _lib.load()
+    A = _rowmajor(_f32(A, 'gemm_nt_rows A'))
+    B = _rowmajor(_f32(B, 'gemm_nt_rows B'))
+    M, K = A.shape
+    N = B.shape[0]
+    if B.shape[1] != K:
+        raise A4NTError('gemm_nt_rows: inner dimensions differ (%d vs %d)' % (K, B.shape[1]))
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+        beta = 0
+    assert out.dim() == 2 and (out.stride(1) == 1 or out.shape[1] == 1)
+    check(lib.a4nt_sgemm_nt_rows(M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out), int(beta), _s()),
+          'a4nt_sgemm_nt_rows')
     return out
 
 

@@ -40,6 +40,19 @@ int a4nt_sgemm(int transA, int transB, int M, int N, int K, const float* A, int 
 /* Workgroup tile edge (128 or 64) a4nt_sgemm uses for this shape; lets the caller label a launch for
  * profiling.  Nothing in the reference corresponds (torch picks its BLAS kernel internally). */
 int a4nt_sgemm_tile(int M, int N, int ksplit);
+/* k-groups (sets of 4 waves, each walking its own share of the workgroup's K range) of the 64x64-tile
+ * launches: 0 = chosen per launch (default), 1 / 2 / 4 = pinned, for benchmarks.  Results differ only
+ * in the fp32 summation order over K.  Nothing in the reference corresponds. */
+int a4nt_sgemm_set_kgroups(int n);
+
+/* C[M,N] (+)= A[M,K] * B[N,K]^T for few rows and 16 <= K <= 512 (K % 16 == 0, A and B rows 16-byte aligned):
+ * A stays in registers (16 rows x K per wave), 16-column blocks of B stream through LDS once per 128 rows.
+ * Replaces: the d(sample) += d(emb) * E^T step of autograd's backward of samp.mm(embedding) inside the
+ * sampling loop (char_translator.py:381-385), one decoder step at a time.
+ * a4nt_sgemm_nt_rows_ok tells whether a shape qualifies (otherwise use a4nt_sgemm). */
+int a4nt_sgemm_nt_rows_ok(int M, int N, int K, int lda, int ldb);
+int a4nt_sgemm_nt_rows(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                       int beta, void* stream);
 
 /* C[M,N] (+)= A[M,K] * op(B) (+ bias) for few rows (M = the batch of ONE decoder step): no LDS, one wave
  * per 16-row x 64/80-column tile and K slab, v_mfma_f32_16x16x4_f32 fed from a register ring.

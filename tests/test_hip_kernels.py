@@ -75,6 +75,52 @@ def test_sgemm_skinny(ops, M, N, K, tB):
         assert_close(ops.slab_reduce(slabs), ref.float(), 2e-6, 'skinny split-K')
 
 
+@pytest.mark.parametrize('M,N,K', [(128, 10001, 512), (100, 1000, 256), (7, 33, 16), (300, 2049, 128), (128, 4000, 496),
+                                   (512, 1500, 512)])
+def test_sgemm_nt_rows(ops, M, N, K):
+    A, B = _rand(M, K, seed=51), _rand(N, K, seed=52)
+    ref = A.double() @ B.double().t()
+    assert_close(ops.gemm_nt_rows(A.cuda(), B.cuda()), ref.float(), 2e-6, 'nt_rows')
+    # accumulate into a strided, unaligned view (one step's rows of the [n*B, V] d(sample) buffer); A a column
+    # window of a wider matrix, as the generator's backward pass passes it
+    wide = _rand(M, K + 64, seed=53).cuda()
+    wide[:, 64:] = A.cuda()
+    big = _rand(M + 3, N + 5, seed=54).cuda()
+    view = big[1:M + 1, 3:N + 3]
+    before = view.clone()
+    ops.gemm_nt_rows(wide[:, 64:], B.cuda(), out=view, beta=1)
+    assert_close(view, (before.cpu().double() + ref).float(), 2e-6, 'nt_rows beta=1 strided')
+    ref_big = _rand(M + 3, N + 5, seed=54)
+    assert torch.equal(big[0].cpu(), ref_big[0]) and torch.equal(big[:, :3].cpu(), ref_big[:, :3])
+    assert torch.equal(big[M + 1:].cpu(), ref_big[M + 1:]) and torch.equal(big[:, N + 3:].cpu(), ref_big[:, N + 3:])
+
+
+def test_sgemm_nt_rows_rejects(ops):
+    with pytest.raises(Exception):
+        ops.gemm_nt_rows(_rand(8, 520, seed=1).cuda(), _rand(64, 520, seed=2).cuda())     # K > 512
+    with pytest.raises(Exception):
+        ops.gemm_nt_rows(_rand(8, 100, seed=1).cuda(), _rand(64, 100, seed=2).cuda())     # K % 16 != 0
+
+
+@pytest.mark.parametrize('kg', [1, 2, 4])
+def test_sgemm_kgroups(ops, kg):
+    from a4nt_amd import _lib
+    lib = _lib.load()
+    try:
+        _lib.check(lib.a4nt_sgemm_set_kgroups(kg), 'kgroups')
+        for (M, N, K, tA, tB, ks) in [(128, 512, 10001, 0, 1, 16), (128, 1024, 2048, 0, 0, 4), (70, 130, 100, 0, 1, 1),
+                                      (64, 64, 16, 1, 0, 1), (128, 700, 37, 0, 0, 1), (90, 200, 1000, 1, 0, 3)]:
+            A = _rand(K, M, seed=61) if tA else _rand(M, K, seed=61)
+            B = _rand(N, K, seed=62) if tB else _rand(K, N, seed=62)
+            ref = (A.t() if tA else A).double() @ (B.t() if tB else B).double()
+            out = ops.gemm(A.cuda(), B.cuda(), bool(tA), bool(tB), ksplit=ks)
+            got = ops.slab_reduce(out) if ks > 1 else out
+            assert_close(got, ref.float(), 2e-6 * max(1.0, (K / 1000.0) ** 0.5), 'kgroups %d %s' % (kg, (M, N, K)))
+    finally:
+        _lib.check(lib.a4nt_sgemm_set_kgroups(0), 'kgroups')
+    assert lib.a4nt_sgemm_set_kgroups(3) != 0
+
+
 def test_sgemm_splitk(ops):
     A, B = _rand(128, 10001, seed=5), _rand(512, 10001, seed=6)
     ref = A.double() @ B.double().t()

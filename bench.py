@@ -190,6 +190,8 @@ def main():
                     help='kernel timed with HIP events inside the timed region (default: the kernel with the '
                          'largest share of the step in profiles/: sgemm_kernel<false,true,2,2,2>)')
     ap.add_argument('--no-extra-rooflines', action='store_true')
+    ap.add_argument('--lstm-workgroups', type=int, default=0, choices=(0, 256, 512),
+                    help='persistent LSTM sweep residency (0: 512 on one GPU, 256 beside RCCL kernels when N > 1)')
     args = ap.parse_args()
     wl = set_workload(args.workload)
     if args.batch is None:
@@ -204,7 +206,9 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     import a4nt_amd as impl
     from a4nt_amd import ops
-    if world > 1:
+    if args.lstm_workgroups:
+        impl.lstm_set_max_workgroups(args.lstm_workgroups)
+    elif world > 1:
         # leave half of every CU's registers to the RCCL kernels that run beside the persistent LSTM sweeps
         impl.lstm_set_max_workgroups(256)
 

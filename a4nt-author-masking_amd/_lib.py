@@ -11,6 +11,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4NT_HIP_LIB') or os.path.join(_HERE, 'liba4nt_hip.so')
 
 P = c_void_p
+
+
+class LstmFwdProblem(ctypes.Structure):      # a4nt_lstm_fwd_problem
+    _fields_ = [('T', c_int), ('B', c_int)] + [(n, c_void_p) for n in (
+        'gx', 'gc', 'whh', 'h0', 'c0', 'lens', 'hs', 'gates', 'cs', 'hN', 'cN', 'xch', 'sync')]
+
+
+class LstmBwdProblem(ctypes.Structure):      # a4nt_lstm_bwd_problem
+    _fields_ = [('T', c_int), ('B', c_int)] + [(n, c_void_p) for n in (
+        'whh', 'gates', 'cs', 'c0', 'lens', 'dhs', 'dhN', 'dcN', 'dgates', 'dh0', 'dc0', 'xch', 'sync')]
+
+
 _SIGS = {
     'a4nt_last_error': (c_char_p, []),
     'a4nt_version': (c_int, []),
@@ -29,6 +41,11 @@ _SIGS = {
     'a4nt_lstm_sync_words': (c_int, [c_int, c_int]),
     'a4nt_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'a4nt_lstm_seq_bwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'a4nt_lstm_pair_geometry': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    'a4nt_lstm_pair_xch_floats': (c_longlong, [c_int, c_int, c_int, c_int]),
+    'a4nt_lstm_pair_sync_words': (c_int, [c_int, c_int]),
+    'a4nt_lstm_seq_fwd_pair': (c_int, [c_int, POINTER(LstmFwdProblem), POINTER(LstmFwdProblem), P]),
+    'a4nt_lstm_seq_bwd_pair': (c_int, [c_int, POINTER(LstmBwdProblem), POINTER(LstmBwdProblem), P]),
     'a4nt_lstm_check_timeout': (c_int, [P, c_int, P]),
     'a4nt_lstm_dec_step': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
     'a4nt_lstm_cell_bwd': (c_int, [c_int, c_int, P, P, P, P, c_int, c_longlong, P, c_int, P, P, P]),

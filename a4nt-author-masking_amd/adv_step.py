@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .gen_decode import SoftSamples
 
 
@@ -53,7 +54,17 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
         samples_srt = samples_srt.detach()
     drop = backprop_for == 'eval'
     real_out = None
-    if real_batch is not None and hasattr(modelEval, 'forward_classify_multi'):
+    cyc = None
+    ml_cycle = cycle_compute and backprop_for != 'eval' and cycle_loss_type == 'ml'
+    if ml_cycle and real_batch is None:
+        # The discriminator over the generated batch and the reconstruction pass over the same batch do not use
+        # each other's results: their LSTM layers are launched pairwise (ops.paired), forward and backward.
+        reverse_inp = samples_srt.prepend_token(_start_id(append_symb))
+        eval_out, cyc = ops.paired(
+            lambda: modelEval.forward_classify(samples_srt, adv_inp=True, lens=len_sorted.tolist(), drop=drop),
+            lambda: modelGen.forward_mltrain_loss(reverse_inp, len_sorted.tolist(), inps, lens, targs, auths=auths,
+                                                  adv_inp=True, sort_enc=rev_dev))
+    elif real_batch is not None and hasattr(modelEval, 'forward_classify_multi'):
         eval_out, real_out = modelEval.forward_classify_multi(
             [(samples_srt, len_sorted.tolist(), True), (real_batch[0], real_batch[1], False)], drop=drop)
     else:
@@ -63,8 +74,10 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
     logits = eval_out[0].index_select(0, rev_dev)
     out = (logits, eval_out[1], samples, gen_lens, char_outs)
     if cycle_compute and backprop_for != 'eval':
-        reverse_inp = samples_srt.prepend_token(_start_id(append_symb))
-        if cycle_loss_type != 'ml':
+        if cyc is not None:
+            out = out + (cyc,)
+        elif cycle_loss_type != 'ml':
+            reverse_inp = samples_srt.prepend_token(_start_id(append_symb))
             # reverse translation: a second, differentiable free-running generation from the soft samples (:165-174)
             rev, rev_lens, rev_chars = modelGen.forward_advers_gen(
                 reverse_inp, len_sorted.tolist(), soft_samples=True, end_c=end_c, n_max=maxlen, temp=temp, auths=auths,
@@ -74,6 +87,7 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
             out = out + (rev.index_select_batch(rev_dev), rev_lens.index_select(0, rev_dev),
                          [rc.index_select(0, rev_dev) for rc in rev_chars])
         else:
+            reverse_inp = samples_srt.prepend_token(_start_id(append_symb))
             cyc = modelGen.forward_mltrain_loss(reverse_inp, len_sorted.tolist(), inps, lens, targs, auths=auths,
                                                 adv_inp=True, sort_enc=rev_dev)
             out = out + (cyc,)

@@ -29,7 +29,7 @@
 #define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = 0;
 #define STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[k] += n_ - st_prev; st_prev = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STAMP_FLUSH(sync, G) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long* d_ = (unsigned long long*)((sync) + 32 * (G) + 8); for (int k_ = 0; k_ < 8; ++k_) d_[k_] = st_acc[k_]; } } while (0)
+#define STAMP_FLUSH(sync, G) do { if (bid == 0 && threadIdx.x == 0) { unsigned long long* d_ = (unsigned long long*)((sync) + 32 * (G) + 8); for (int k_ = 0; k_ < 8; ++k_) d_[k_] = st_acc[k_]; } } while (0)
 #define STAMP_WAITV() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
 #define STAMP_DECL
@@ -63,12 +63,12 @@ struct LstmFwdArgs {
 };
 
 template <int MT, int NJ>
-__global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
+__device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bid) {
     __shared__ __attribute__((aligned(16))) float part[4][MT][16 * PSTR];
     __shared__ __attribute__((aligned(16))) float hstage[MT][256];
     __shared__ int s_ok;
 
-    const int g = blockIdx.x % a.G, j = blockIdx.x / a.G;
+    const int g = bid % a.G, j = bid / a.G;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H = a.H, H4 = 4 * a.H;
     constexpr int nj = NJ;                 // 16-wide k blocks in this wave's K quarter (H = 64*NJ)
@@ -276,6 +276,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // backward sweep
 // ---------------------------------------------------------------------------------------------
+template <int MT, int NJ>
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) { lstm_fwd_body<MT, NJ>(a, blockIdx.x); }
+
+// Two independent sweeps in one launch (a4nt_lstm_seq_fwd_pair): workgroups [0, nA) run problem a, the rest
+// problem b, each with its own exchange buffer and counters.  Neither sweep fills the chip alone (128 rows
+// = 256 of 512 resident workgroups), and each step of a sweep is mostly hand-off latency: side by side,
+// one sweep's MFMA phase runs under the other's waits.
+template <int MT, int NJ>
+__global__ __launch_bounds__(256) void lstm_fwd2_kernel(LstmFwdArgs a, LstmFwdArgs b, int nA) {
+    const bool first = (int)blockIdx.x < nA;
+    const LstmFwdArgs s = first ? a : b;
+    lstm_fwd_body<MT, NJ>(s, first ? (int)blockIdx.x : (int)blockIdx.x - nA);
+}
+
 struct LstmBwdArgs {
     int T, B, H, G, NW;
     const float* whh;       // [4H][H]
@@ -293,7 +307,7 @@ struct LstmBwdArgs {
 };
 
 template <int MT, int NJ>
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
+__device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bid) {
     // Workgroup j of a row group owns hidden units [16j, 16j+16): it computes dgates_t for those units
     // (64 of the 4H gate rows) and multiplies them, straight from LDS, with ITS 64 rows of W_hh, which
     // gives a partial dh_{t-1} for ALL H columns; the partials are exchanged as 16x16 blocks and every
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][MT][16 * 20];  // per-wave partial sums [col][row]
     __shared__ int s_ok;
 
-    const int g = blockIdx.x % a.G, j = blockIdx.x / a.G;
+    const int g = bid % a.G, j = bid / a.G;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H = a.H, H4 = 4 * a.H;
     const int u0 = 16 * j;
@@ -501,6 +515,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
     }
 }
 
+template <int MT, int NJ>
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) { lstm_bwd_body<MT, NJ>(a, blockIdx.x); }
+
+template <int MT, int NJ>
+__global__ __launch_bounds__(256) void lstm_bwd2_kernel(LstmBwdArgs a, LstmBwdArgs b, int nA) {
+    const bool first = (int)blockIdx.x < nA;
+    const LstmBwdArgs s = first ? a : b;
+    lstm_bwd_body<MT, NJ>(s, first ? (int)blockIdx.x : (int)blockIdx.x - nA);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -633,4 +657,113 @@ extern "C" int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const fl
     dim3 grid(G * a.NW), block(256);
     A4NT_DISPATCH_LSTM(lstm_bwd_kernel, mt, H / 64, grid, block, s, a);
     return a4nt_check_launch("lstm_seq_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// two sweeps in one launch
+// ---------------------------------------------------------------------------------------------
+struct a4nt_lstm_fwd_problem {      // mirrors include/a4nt_hip.h
+    int T, B;
+    const float* gx; const float* gc; const float* whh; const float* h0; const float* c0; const int* lens;
+    float* hs; float* gates; float* cs; float* hN; float* cN; float* xch; unsigned* sync;
+};
+struct a4nt_lstm_bwd_problem {
+    int T, B;
+    const float* whh; const float* gates; const float* cs; const float* c0; const int* lens;
+    const float* dhs; const float* dhN; const float* dcN;
+    float* dgates; float* dh0; float* dc0; float* xch; unsigned* sync;
+};
+
+#define A4NT_DISPATCH_LSTM2(KERNEL, mt, nj, grid, block, s, a, b, nA)                                             \
+    do {                                                                                                         \
+        if (mt == 1 && nj == 1) hipLaunchKernelGGL((KERNEL<1, 1>), grid, block, 0, s, a, b, nA);                  \
+        else if (mt == 1 && nj == 2) hipLaunchKernelGGL((KERNEL<1, 2>), grid, block, 0, s, a, b, nA);             \
+        else if (mt == 1 && nj == 4) hipLaunchKernelGGL((KERNEL<1, 4>), grid, block, 0, s, a, b, nA);             \
+        else if (mt == 1 && nj == 8) hipLaunchKernelGGL((KERNEL<1, 8>), grid, block, 0, s, a, b, nA);             \
+        else if (mt == 2 && nj == 1) hipLaunchKernelGGL((KERNEL<2, 1>), grid, block, 0, s, a, b, nA);             \
+        else if (mt == 2 && nj == 2) hipLaunchKernelGGL((KERNEL<2, 2>), grid, block, 0, s, a, b, nA);             \
+        else if (mt == 2 && nj == 4) hipLaunchKernelGGL((KERNEL<2, 4>), grid, block, 0, s, a, b, nA);             \
+        else hipLaunchKernelGGL((KERNEL<2, 8>), grid, block, 0, s, a, b, nA);                                     \
+    } while (0)
+
+// Geometry of a pair: both sweeps use the same rows-per-workgroup (16*mt), and together they must fit the
+// workgroup budget.  Returns A4NT_ERR_ARG (no error text) when the pair does not fit: run them one by one.
+extern "C" int a4nt_lstm_pair_geometry(int B0, int B1, int H, int* mt_out, int* g0_out, int* g1_out) {
+    if (B0 <= 0 || B1 <= 0 || bad_h(H) || H > 512) return A4NT_ERR_ARG;
+    const int NW = H / 16;
+    for (int mt = 1; mt <= 2; mt *= 2) {
+        const int g0 = (B0 + 16 * mt - 1) / (16 * mt), g1 = (B1 + 16 * mt - 1) / (16 * mt);
+        if ((long long)(g0 + g1) * NW <= (mt == 1 ? g_max_wgs : 256)) { *mt_out = mt; *g0_out = g0; *g1_out = g1; return A4NT_OK; }
+    }
+    return A4NT_ERR_ARG;
+}
+// exchange floats / sync words of one sweep of a pair (mt from a4nt_lstm_pair_geometry)
+extern "C" long long a4nt_lstm_pair_xch_floats(int B, int H, int mt, int backward) {
+    if (B <= 0 || bad_h(H) || (mt != 1 && mt != 2)) return -1;
+    const long long G = (B + 16 * mt - 1) / (16 * mt);
+    return 2 * G * (H / 16) * mt * 256 * (backward ? (H / 16) : 1);
+}
+extern "C" int a4nt_lstm_pair_sync_words(int B, int mt) {
+    if (B <= 0 || (mt != 1 && mt != 2)) return -1;
+    return 32 * ((B + 16 * mt - 1) / (16 * mt)) + 32;
+}
+
+extern "C" int a4nt_lstm_seq_fwd_pair(int H, const a4nt_lstm_fwd_problem* p0, const a4nt_lstm_fwd_problem* p1, void* stream) {
+    if (!p0 || !p1) { a4nt_set_error("a4nt_lstm_seq_fwd_pair: null problem"); return A4NT_ERR_ARG; }
+    int mt, G[2];
+    if (a4nt_lstm_pair_geometry(p0->B, p1->B, H, &mt, &G[0], &G[1]) != A4NT_OK) {
+        a4nt_set_error("a4nt_lstm_seq_fwd_pair: %d + %d rows at H=%d do not fit one launch", p0->B, p1->B, H);
+        return A4NT_ERR_ARG;
+    }
+    const a4nt_lstm_fwd_problem* p[2] = {p0, p1};
+    LstmFwdArgs a[2];
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < 2; ++i) {
+        if (p[i]->T <= 0 || !p[i]->gx || !p[i]->whh || !p[i]->hs || !p[i]->xch || !p[i]->sync || misaligned(p[i]->whh) ||
+            misaligned(p[i]->xch) || (i == 1 && (p0->xch == p1->xch || p0->sync == p1->sync))) {
+            a4nt_set_error("a4nt_lstm_seq_fwd_pair: bad arguments in problem %d (T=%d, null, misaligned or shared scratch)", i, p[i]->T);
+            return A4NT_ERR_ARG;
+        }
+        if (hipMemsetAsync(p[i]->sync, 0, (size_t)(32 * G[i] + 32) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_fwd_pair memset");
+        LstmFwdArgs& q = a[i];
+        q.T = p[i]->T; q.B = p[i]->B; q.H = H; q.G = G[i]; q.NW = H / 16;
+        q.gx = p[i]->gx; q.whh = p[i]->whh; q.h0 = p[i]->h0; q.c0 = p[i]->c0; q.lens = p[i]->lens;
+        q.cg = p[i]->gc; q.ptab = nullptr; q.tok = nullptr; q.val = nullptr;
+        q.hs = p[i]->hs; q.gates = p[i]->gates; q.cs = p[i]->cs; q.hN = p[i]->hN; q.cN = p[i]->cN; q.hx = p[i]->xch;
+        q.sync = p[i]->sync; q.mode = 0; q.step0 = 0;
+    }
+    const int nA = G[0] * (H / 16);
+    dim3 grid((G[0] + G[1]) * (H / 16)), block(256);
+    A4NT_DISPATCH_LSTM2(lstm_fwd2_kernel, mt, H / 64, grid, block, s, a[0], a[1], nA);
+    return a4nt_check_launch("lstm_seq_fwd_pair");
+}
+
+extern "C" int a4nt_lstm_seq_bwd_pair(int H, const a4nt_lstm_bwd_problem* p0, const a4nt_lstm_bwd_problem* p1, void* stream) {
+    if (!p0 || !p1) { a4nt_set_error("a4nt_lstm_seq_bwd_pair: null problem"); return A4NT_ERR_ARG; }
+    int mt, G[2];
+    if (a4nt_lstm_pair_geometry(p0->B, p1->B, H, &mt, &G[0], &G[1]) != A4NT_OK) {
+        a4nt_set_error("a4nt_lstm_seq_bwd_pair: %d + %d rows at H=%d do not fit one launch", p0->B, p1->B, H);
+        return A4NT_ERR_ARG;
+    }
+    const a4nt_lstm_bwd_problem* p[2] = {p0, p1};
+    LstmBwdArgs a[2];
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < 2; ++i) {
+        if (p[i]->T <= 0 || !p[i]->whh || !p[i]->gates || !p[i]->cs || !p[i]->dgates || !p[i]->xch || !p[i]->sync ||
+            misaligned(p[i]->xch) || (i == 1 && (p0->xch == p1->xch || p0->sync == p1->sync))) {
+            a4nt_set_error("a4nt_lstm_seq_bwd_pair: bad arguments in problem %d (T=%d, null, misaligned or shared scratch)", i, p[i]->T);
+            return A4NT_ERR_ARG;
+        }
+        if (hipMemsetAsync(p[i]->sync, 0, (size_t)(32 * G[i] + 32) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_bwd_pair memset");
+        LstmBwdArgs& q = a[i];
+        q.T = p[i]->T; q.B = p[i]->B; q.H = H; q.G = G[i]; q.NW = H / 16;
+        q.whh = p[i]->whh; q.gates = p[i]->gates; q.cs = p[i]->cs; q.c0 = p[i]->c0; q.lens = p[i]->lens;
+        q.dhs = p[i]->dhs; q.dhN = p[i]->dhN; q.dcN = p[i]->dcN;
+        q.dgates = p[i]->dgates; q.dh0 = p[i]->dh0; q.dc0 = p[i]->dc0; q.gxch = p[i]->xch; q.sync = p[i]->sync;
+        q.need_dh0 = (p[i]->dh0 != nullptr) ? 1 : 0;
+    }
+    const int nA = G[0] * (H / 16);
+    dim3 grid((G[0] + G[1]) * (H / 16)), block(256);
+    A4NT_DISPATCH_LSTM2(lstm_bwd2_kernel, mt, H / 64, grid, block, s, a[0], a[1], nA);
+    return a4nt_check_launch("lstm_seq_bwd_pair");
 }

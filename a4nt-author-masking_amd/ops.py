@@ -5,6 +5,7 @@ liba4nt_hip.so and wires the results into torch.autograd.  There is no CPU / eag
 tensor that is not a float32 CUDA tensor is an error.
 """
 import ctypes
+import threading
 
 import torch
 from torch.autograd import Function
@@ -344,6 +345,85 @@ def lstm_seq_bwd(w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0):
     return dgates, dh0, dc0
 
 
+def lstm_pair_geometry(B0, B1, H):
+    """(mt, g0, g1) when two sweeps of B0 and B1 rows fit one launch at hidden size H, else None."""
+    mt, g0, g1 = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    if _lib.load().a4nt_lstm_pair_geometry(int(B0), int(B1), int(H), ctypes.byref(mt), ctypes.byref(g0),
+                                           ctypes.byref(g1)) != 0:
+        return None
+    return mt.value, g0.value, g1.value
+
+
+def _lstm_pair_ws(dev, B, H, mt, backward, slot):
+    key = (dev.index, B, H, backward, 'pair', mt, slot)
+    if key not in _ws:
+        lib = _lib.load()
+        _lib.init_device(dev.index if dev.index is not None else torch.cuda.current_device())
+        nf = lib.a4nt_lstm_pair_xch_floats(B, H, mt, int(backward))
+        nw = lib.a4nt_lstm_pair_sync_words(B, mt)
+        if nf < 0 or nw < 0:
+            check(1, 'a4nt_lstm pair workspace')
+        xch = torch.zeros(nf, device=dev, dtype=torch.float32)
+        sync = torch.zeros(nw, device=dev, dtype=torch.int32)
+        g = (nw - 32) // 32
+        _ws[key] = (xch, sync, g)
+        _sync_blocks.append((sync, g))
+    return _ws[key]
+
+
+def lstm_seq_fwd_pair(reqs, save=True):
+    """Two forward sweeps in one launch.  reqs: two tuples (gx, w_hh, lens_dev, h0, c0, gc) as for lstm_seq_fwd
+    (same hidden size; lstm_pair_geometry must accept the two batch sizes).  Returns two lstm_seq_fwd results."""
+    lib = _lib.load()
+    H = reqs[0][0].shape[2] // 4
+    dev = reqs[0][0].device
+    mt = lstm_pair_geometry(reqs[0][0].shape[1], reqs[1][0].shape[1], H)[0]
+    probs, outs, keep = [], [], []
+    flops = 0.0
+    for slot, (gx, w_hh, lens_dev, h0, c0, gc) in enumerate(reqs):
+        T, B, _ = gx.shape
+        xch, sync, _g = _lstm_pair_ws(dev, B, H, mt, False, slot)
+        hs_all = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
+        if h0 is None:
+            hs_all[0].zero_()
+        else:
+            hs_all[0].copy_(h0)
+        cs = torch.empty((T, B, H), device=dev, dtype=torch.float32) if save else None
+        hN = torch.empty((B, H), device=dev, dtype=torch.float32)
+        cN = torch.empty((B, H), device=dev, dtype=torch.float32)
+        probs.append(_lib.LstmFwdProblem(T, B, _p(gx), _p(gc), _p(w_hh), _p(h0), _p(c0), _p(lens_dev), _p(hs_all[1:]),
+                                         _p(gx) if save else None, _p(cs), _p(hN), _p(cN), _p(xch), _p(sync)))
+        outs.append((hs_all, cs, hN, cN))
+        flops += 8.0 * T * B * H * H
+    with _Timed('lstm_seq_fwd', flops):
+        check(lib.a4nt_lstm_seq_fwd_pair(H, ctypes.byref(probs[0]), ctypes.byref(probs[1]), _s()), 'a4nt_lstm_seq_fwd_pair')
+    return outs
+
+
+def lstm_seq_bwd_pair(reqs):
+    """Two backward sweeps in one launch.  reqs: two tuples (w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0)
+    as for lstm_seq_bwd.  Returns two (dgates, dh0, dc0)."""
+    lib = _lib.load()
+    H = reqs[0][1].shape[2] // 4
+    dev = reqs[0][1].device
+    mt = lstm_pair_geometry(reqs[0][1].shape[1], reqs[1][1].shape[1], H)[0]
+    probs, outs = [], []
+    flops = 0.0
+    for slot, (w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0) in enumerate(reqs):
+        T, B, _ = gates.shape
+        xch, sync, _g = _lstm_pair_ws(dev, B, H, mt, True, slot)
+        dgates = torch.empty_like(gates)
+        dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
+        dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
+        probs.append(_lib.LstmBwdProblem(T, B, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN),
+                                         _p(dcN), _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync)))
+        outs.append((dgates, dh0, dc0))
+        flops += 8.0 * T * B * H * H
+    with _Timed('lstm_seq_bwd', flops):
+        check(lib.a4nt_lstm_seq_bwd_pair(H, ctypes.byref(probs[0]), ctypes.byref(probs[1]), _s()), 'a4nt_lstm_seq_bwd_pair')
+    return outs
+
+
 # ----------------------------------------------------------------------------------------------
 # autograd operators
 # ----------------------------------------------------------------------------------------------
@@ -436,6 +516,11 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, lens_dev=None, h0=None, c0=None, gc=No
     sweeps over row chunks: rows are independent."""
     x = _f32(x, 'lstm input')
     B, H = x.shape[1], w_hh.shape[1]
+    sched = getattr(_pair_local, 'sched', None)
+    if sched is not None:
+        res = sched.request(_pair_local.me, (x.contiguous(), w_ih, w_hh, b_ih, b_hh, h0, c0, gc, lens_dev))
+        if res is not None:
+            return res
     if lstm_rows_fit(B, H):
         return _LstmLayer.apply(x.contiguous(), w_ih, w_hh, b_ih, b_hh, h0, c0, gc, lens_dev)
     step = B
@@ -447,6 +532,167 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, lens_dev=None, h0=None, c0=None, gc=No
                               sl(c0, a, a + step), sl(gc, a, a + step), sl(lens_dev, a, a + step))
              for a in range(0, B, step)]
     return (torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 0), torch.cat([p[2] for p in parts], 0))
+
+
+class _LstmLayerPair(Function):
+    """Two independent _LstmLayer problems whose sweeps (forward, and later backward) share one launch.
+    Inputs: the nine _LstmLayer inputs of problem 0, then those of problem 1; outputs likewise."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        reqs, saved, meta = [], [], []
+        for k in range(2):
+            x, w_ih, w_hh, b_ih, b_hh, h0, c0, gc, lens_dev = args[9 * k:9 * k + 9]
+            T, B, I = x.shape
+            H = w_hh.shape[1]
+            x2 = x.reshape(T * B, I)
+            gx = gemm(x2, w_ih, transB=True, bias=(b_ih + b_hh)).view(T, B, 4 * H)
+            reqs.append((gx, w_hh.contiguous(), lens_dev, h0, c0, gc))
+            meta.append(((T, B, I, H), (c0 is not None, lens_dev is not None, gc is not None, h0 is not None)))
+            saved.append([x2, w_ih, w_hh, gx, None, None, c0 if c0 is not None else torch.empty(0),
+                          lens_dev if lens_dev is not None else torch.empty(0)])
+        res = lstm_seq_fwd_pair(reqs, save=True)
+        outs = []
+        for k in range(2):
+            hs_all, cs, hN, cN = res[k]
+            saved[k][4], saved[k][5] = cs, hs_all
+            outs += [hs_all[1:], hN, cN]
+        ctx.save_for_backward(*(saved[0] + saved[1]))
+        ctx.meta = meta
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        sv = ctx.saved_tensors
+        reqs, info = [], []
+        for k in range(2):
+            x2, w_ih, w_hh, gates, cs, hs_all, c0, lens_dev = sv[8 * k:8 * k + 8]
+            (T, B, I, H), (has_c0, has_lens, has_gc, has_h0) = ctx.meta[k]
+            nig = ctx.needs_input_grad[9 * k:9 * k + 9]
+            need_h0 = has_h0 and (nig[5] or nig[6])
+            dout, dhN, dcN = [d.contiguous() if d is not None else None for d in douts[3 * k:3 * k + 3]]
+            reqs.append((w_hh.contiguous(), gates, cs, c0 if has_c0 else None, lens_dev if has_lens else None, dout,
+                         dhN, dcN, need_h0))
+            info.append((x2, w_ih, hs_all, T, B, I, H, has_c0, has_gc, has_h0, nig))
+        res = lstm_seq_bwd_pair(reqs)
+        grads = []
+        for k in range(2):
+            dgates, dh0, dc0 = res[k]
+            x2, w_ih, hs_all, T, B, I, H, has_c0, has_gc, has_h0, nig = info[k]
+            dG2 = dgates.view(T * B, 4 * H)
+            dx = gemm(dG2, w_ih).view(T, B, I) if nig[0] else None
+            dw_ih = gemm_auto(dG2, x2, transA=True) if nig[1] else None
+            dw_hh = gemm_auto(dG2, hs_all[:T].view(T * B, H), transA=True) if nig[2] else None
+            db = colsum(dG2) if (nig[3] or nig[4]) else None
+            dgc = colsum(dgates.view(T, B * 4 * H)).view(B, 4 * H) if (has_gc and nig[7]) else None
+            grads += [dx, dw_ih, dw_hh, db, db, (dh0 if has_h0 else None), (dc0 if has_c0 else None), dgc, None]
+        return tuple(grads)
+
+
+# Pairing of the LSTM layers of two independent computations (adv_step.g_update: the discriminator over the
+# generated batch and the reconstruction pass over the same batch).  The two computations run as coroutines
+# (threads that hand one baton back and forth, never concurrently): each runs until its next lstm_layer call;
+# when both have one pending and the pair fits one launch, _LstmLayerPair runs both.
+class _PairScheduler:
+    def __init__(self):
+        self.cv = threading.Condition()
+        self.turn = 0
+        self.done = [False, False]
+        self.pending = [None, None]
+        self.result = [None, None]
+        self.error = [None, None]
+
+    def _other_waiting(self, me):
+        return self.pending[1 - me] is not None and not self.done[1 - me]
+
+    def request(self, me, args):
+        """Called (holding the baton) from lstm_layer inside computation `me`."""
+        other = 1 - me
+        with self.cv:
+            if self.done[other]:
+                return None                                   # alone: the caller runs the single-problem layer
+            if self._other_waiting(me):
+                a = (args, self.pending[other]) if me == 0 else (self.pending[other], args)
+                if _pairable(a[0], a[1]):
+                    outs = _LstmLayerPair.apply(*(a[0] + a[1]))
+                    mine, theirs = (outs[:3], outs[3:]) if me == 0 else (outs[3:], outs[:3])
+                    self.pending[other] = None
+                    self.result[other] = theirs
+                    return mine                               # keep the baton: run on to the next request
+                # not pairable: the other side's layer runs alone (by the other side), then it comes back here
+                self.pending[other] = None
+                self.result[other] = 'solo'
+            # hand the baton over with my request pending
+            self.pending[me] = args
+            self.turn = other
+            self.cv.notify_all()
+            while self.turn != me:
+                self.cv.wait()
+            res, self.result[me] = self.result[me], None
+            if res is None or res == 'solo':                  # the other side finished, or declined the pair
+                self.pending[me] = None
+                return None
+            return res
+
+    def finish(self, me, err=None):
+        with self.cv:
+            self.done[me] = True
+            self.error[me] = err
+            self.turn = 1 - me
+            self.cv.notify_all()
+
+
+def _pairable(a, b):
+    xa, xb = a[0], b[0]
+    Ha, Hb = a[2].shape[1], b[2].shape[1]
+    if Ha != Hb or xa.device != xb.device:
+        return False
+    return lstm_pair_geometry(xa.shape[1], xb.shape[1], Ha) is not None
+
+
+_pair_local = threading.local()
+
+
+def paired(fn0, fn1):
+    """Run fn0() and fn1() -- two computations none of which uses the other's results -- so that their LSTM
+    layers are launched pairwise.  Returns (fn0(), fn1()).  With pairing switched off (PAIR_LSTM = False, or
+    nested use) simply calls them in order."""
+    if not PAIR_LSTM or getattr(_pair_local, 'sched', None) is not None:
+        return fn0(), fn1()
+    sched = _PairScheduler()
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    grad_mode = torch.is_grad_enabled()
+    out = [None, None]
+
+    def run(me, fn):
+        with sched.cv:
+            while sched.turn != me:
+                sched.cv.wait()
+        _pair_local.sched, _pair_local.me = sched, me
+        err = None
+        try:
+            if dev is not None:
+                torch.cuda.set_device(dev)
+            with torch.set_grad_enabled(grad_mode):
+                out[me] = fn()
+        except BaseException as e:      # re-raised in the caller's thread
+            err = e
+        finally:
+            _pair_local.sched = None
+            sched.finish(me, err)
+
+    threads = [threading.Thread(target=run, args=(k, f), daemon=True) for k, f in enumerate((fn0, fn1))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in sched.error:
+        if e is not None:
+            raise e
+    return out[0], out[1]
+
+
+PAIR_LSTM = True
 
 
 class _Embed(Function):

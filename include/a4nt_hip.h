@@ -98,6 +98,32 @@ int a4nt_lstm_seq_fwd(int T, int B, int H, const float* gx, const float* gc, con
 int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const float* gates, const float* cs, const float* c0,
                       const int* lens, const float* dhs, const float* dhN, const float* dcN, float* dgates,
                       float* dh0, float* dc0, float* xch, unsigned* sync, void* stream);
+
+/* Two independent sweeps in ONE launch: workgroups of both problems are co-resident, so one sweep's MFMA
+ * phase runs under the other's hand-off waits (two 128-row sweeps at H = 512 each fill half of the 512
+ * resident workgroups).  Fields as the arguments of a4nt_lstm_seq_fwd / a4nt_lstm_seq_bwd; every problem has
+ * its own xch / sync scratch, sized by a4nt_lstm_pair_xch_floats / a4nt_lstm_pair_sync_words with the mt
+ * a4nt_lstm_pair_geometry returns (it fails, without an error text, when the pair does not fit one launch or
+ * H > 512: run the sweeps one by one then).  Results are those of the single-sweep entry points, bit for bit.
+ * Nothing in the reference corresponds to the pairing itself (its nn.LSTM calls run one after another):
+ * the pair is the discriminator's layer over the generated batch next to the reconstruction encoder /
+ * decoder layer over the same batch in the generator update (adv_step.g_update). */
+typedef struct {
+    int T, B;
+    const float* gx; const float* gc; const float* whh; const float* h0; const float* c0; const int* lens;
+    float* hs; float* gates; float* cs; float* hN; float* cN; float* xch; unsigned* sync;
+} a4nt_lstm_fwd_problem;
+typedef struct {
+    int T, B;
+    const float* whh; const float* gates; const float* cs; const float* c0; const int* lens;
+    const float* dhs; const float* dhN; const float* dcN;
+    float* dgates; float* dh0; float* dc0; float* xch; unsigned* sync;
+} a4nt_lstm_bwd_problem;
+int a4nt_lstm_pair_geometry(int B0, int B1, int H, int* mt_out, int* g0_out, int* g1_out);
+long long a4nt_lstm_pair_xch_floats(int B, int H, int mt, int backward);
+int a4nt_lstm_pair_sync_words(int B, int mt);
+int a4nt_lstm_seq_fwd_pair(int H, const a4nt_lstm_fwd_problem* p0, const a4nt_lstm_fwd_problem* p1, void* stream);
+int a4nt_lstm_seq_bwd_pair(int H, const a4nt_lstm_bwd_problem* p0, const a4nt_lstm_bwd_problem* p1, void* stream);
 /* Synchronises `stream` and reports A4NT_ERR_TIMEOUT if a sweep raised its timeout word. */
 int a4nt_lstm_check_timeout(const unsigned* sync, int groups, void* stream);
 

@@ -203,6 +203,88 @@ def test_lstm_layer_fwd_bwd(ops, T, B, I, H, ragged):
     assert_close(c0g.grad, c0c.grad, TOLG, 'lstm dc0')
 
 
+def _stack_loss(ops, P, x, lens_dev, up):
+    """Two stacked layers (the second one's input depends on the first) and a scalar loss."""
+    o1, _, _ = ops.lstm_layer(x, P['w_ih0'], P['w_hh0'], P['b0'], P['b0b'], lens_dev)
+    o2, hN, cN = ops.lstm_layer(o1, P['w_ih1'], P['w_hh1'], P['b1'], P['b1b'], lens_dev)
+    return (o2 * up).sum() + hN.sum() - cN.sum()
+
+
+def _stack_params(I, H, seed):
+    mk = lambda *sh, k: _rand(*sh, seed=seed + k, scale=0.2).cuda().requires_grad_(True)
+    return {'w_ih0': mk(4 * H, I, k=0), 'w_hh0': mk(4 * H, H, k=1), 'b0': mk(4 * H, k=2), 'b0b': mk(4 * H, k=3),
+            'w_ih1': mk(4 * H, H, k=4), 'w_hh1': mk(4 * H, H, k=5), 'b1': mk(4 * H, k=6), 'b1b': mk(4 * H, k=7)}
+
+
+@pytest.mark.parametrize('H,B0,B1,T0,T1,wgs', [(64, 20, 7, 6, 9, 512), (512, 128, 128, 5, 6, 512), (512, 128, 128, 4, 4, 256),
+                                               (128, 300, 40, 5, 3, 512), (1024, 16, 16, 3, 3, 512)])
+def test_lstm_paired_equals_sequential(ops, H, B0, B1, T0, T1, wgs):
+    """ops.paired: two independent two-layer stacks whose layers are launched pairwise (one persistent launch per
+    pair, forward and backward) give, bit for bit, what running them one after the other gives.  The last two
+    cases do not fit one launch / one kernel instantiation: the layers then run one by one inside paired()."""
+    ops.lstm_set_max_workgroups(wgs)
+    try:
+        I = 32
+        g = torch.Generator().manual_seed(5)
+        res = {}
+        for mode in ('seq', 'pair'):
+            PA, PB = _stack_params(I, H, 100), _stack_params(I, H, 200)
+            xa = _rand(T0, B0, I, seed=1).cuda().requires_grad_(True)
+            xb = _rand(T1, B1, I, seed=2).cuda().requires_grad_(True)
+            la = torch.randint(1, T0 + 1, (B0,), generator=torch.Generator().manual_seed(3)).int().cuda()
+            upa, upb = _rand(T0, B0, H, seed=7).cuda(), _rand(T1, B1, H, seed=8).cuda()
+            fa = lambda: _stack_loss(ops, PA, xa, la, upa)
+            fb = lambda: _stack_loss(ops, PB, xb, None, upb)
+            ops.PAIR_LSTM = mode == 'pair'
+            la_, lb_ = ops.paired(fa, fb)
+            (la_ + 2 * lb_).backward()
+            ops.check_timeouts()
+            res[mode] = [la_.detach(), lb_.detach(), xa.grad, xb.grad] + [PA[k].grad for k in sorted(PA)] + \
+                        [PB[k].grad for k in sorted(PB)]
+        for a, b in zip(res['seq'], res['pair']):
+            if a.dim() == 1:        # bias gradients: a4nt_colsum adds its row chunks with atomics (order varies run to run)
+                assert_close(b, a, 2e-6, 'bias gradient')
+            else:
+                assert torch.equal(a, b)
+    finally:
+        ops.PAIR_LSTM = True
+        ops.lstm_set_max_workgroups(512)
+
+
+def test_lstm_paired_uneven_and_errors(ops):
+    """One side has three layers, the other one; a side that raises surfaces in the caller."""
+    H, I, T, B = 64, 16, 4, 6
+    P = _stack_params(I, H, 300)
+    x = _rand(T, B, I, seed=4).cuda()
+
+    def three():
+        o, _, _ = ops.lstm_layer(x, P['w_ih0'], P['w_hh0'], P['b0'], P['b0b'])
+        o, _, _ = ops.lstm_layer(o, P['w_ih1'], P['w_hh1'], P['b1'], P['b1b'])
+        o, _, _ = ops.lstm_layer(o, P['w_ih1'], P['w_hh1'], P['b1'], P['b1b'])
+        return o
+
+    def one():
+        return ops.lstm_layer(x, P['w_ih0'], P['w_hh0'], P['b0'], P['b0b'])[0]
+
+    ops.PAIR_LSTM = False
+    r3, r1 = three(), one()
+    ops.PAIR_LSTM = True
+    p3, p1 = ops.paired(three, one)
+    q1, q3 = ops.paired(one, three)
+    assert torch.equal(p3, r3) and torch.equal(p1, r1) and torch.equal(q3, r3) and torch.equal(q1, r1)
+    assert ops.paired(lambda: 1, lambda: 2) == (1, 2)
+
+    def boom():
+        ops.lstm_layer(x, P['w_ih0'], P['w_hh0'], P['b0'], P['b0b'])
+        raise ValueError('boom')
+
+    with pytest.raises(ValueError):
+        ops.paired(one, boom)
+    with pytest.raises(ValueError):
+        ops.paired(boom, three)
+    ops.check_timeouts()
+
+
 def test_lstm_loop_invariant_gate_term(ops):
     """gc: the hoisted ctxt*W_ic^T term equals feeding [ctxt, x_t] at every step."""
     T, B, I, Hc, H = 6, 9, 20, 30, 64

@@ -216,11 +216,16 @@ __global__ __launch_bounds__(256) void nll_rows_kernel(int V, float* logits, int
         if (tid == 0) loss_rows[r] = 0.f;
         return;
     }
-    float m = -INFINITY;
-    for (int v = tid; v < V; v += NT) m = fmaxf(m, x[v]);
-    m = block_max(m, red);
-    float s = 0.f;
-    for (int v = tid; v < V; v += NT) s += expf(x[v] - m);
+    // one pass for max and sum: per-thread running (max, sum of exp relative to it), rescaled when the max moves
+    float ml = -INFINITY, sl = 0.f;
+    for (int v = tid; v < V; v += NT) {
+        const float xv = x[v];
+        const float mn = fmaxf(ml, xv);
+        sl = sl * expf(ml - mn) + expf(xv - mn);         // expf(-inf) = 0 on the first element
+        ml = mn;
+    }
+    const float m = block_max(ml, red);
+    float s = (ml == -INFINITY) ? 0.f : sl * expf(ml - m);
     s = block_sum(s, red);
     const float lse = m + logf(s);
     if (tid == 0) loss_rows[r] = lse - x[tg];

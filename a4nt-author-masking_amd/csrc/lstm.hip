@@ -372,6 +372,32 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
             }
     }
 
+    // Saved activations, cell states and upstream dh of a step do not depend on the recurrence: they are loaded one
+    // step ahead (issued before the wait for the peers' partials), with clamped, always-valid addresses so that the
+    // loads are unconditional; validity is applied to the values.
+    struct StepIn { float ig, fg, gg, og, cp, dhs; };
+    auto load_step = [&](int t, StepIn (&p)[MT]) {
+        const int tc = max(t, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rb = min(r0 + 16 * mt + crow, a.B - 1);
+            const long long o = ((long long)tc * a.B + rb);
+            const float* pg = a.gates + o * H4 + u0 + cunit;
+            p[mt].ig = pg[0]; p[mt].fg = pg[H]; p[mt].gg = pg[2 * H]; p[mt].og = pg[3 * H];
+            if (tc > 0) p[mt].cp = a.cs[(o - a.B) * H + u0 + cunit];
+            else p[mt].cp = a.c0 ? a.c0[(long long)rb * H + u0 + cunit] : 0.f;
+            p[mt].dhs = a.dhs ? a.dhs[o * H + u0 + cunit] : 0.f;
+        }
+    };
+    StepIn cur[MT];
+    float ct_cur[MT];           // c_t of the current step = c_prev of the step processed before it
+    load_step(Tg - 1, cur);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int rb = min(r0 + 16 * mt + crow, a.B - 1);
+        ct_cur[mt] = Tg > 0 ? a.cs[((long long)(Tg - 1) * a.B + rb) * H + u0 + cunit] : 0.f;
+    }
+
     int s = 0;   // published steps so far
     for (int t = Tg - 1; t >= 0; --t, ++s) {
         const int par = s & 1;
@@ -381,30 +407,22 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
         for (int mt = 0; mt < MT; ++mt) {
             const int rb = r0 + 16 * mt + crow;
             float dp[4] = {0.f, 0.f, 0.f, 0.f};
-            if (rb < a.B) {
-                const long long o = ((long long)t * a.B + rb);
-                if (t < len_r[mt]) {
-                    const float* pg = a.gates + o * H4 + u0 + cunit;
-                    const float ig = pg[0], fg = pg[H], gg = pg[2 * H], og = pg[3 * H];
-                    const float ct = a.cs[o * H + u0 + cunit];
-                    float cp;
-                    if (t > 0) cp = a.cs[(o - a.B) * H + u0 + cunit];
-                    else cp = a.c0 ? a.c0[(long long)rb * H + u0 + cunit] : 0.f;
-                    float dh = dh_rec[mt];
-                    float dc = dc_next[mt];
-                    if (a.dhs) dh += a.dhs[o * H + u0 + cunit];
-                    if (t == len_r[mt] - 1) {
-                        if (a.dhN) dh += a.dhN[(long long)rb * H + u0 + cunit];
-                        if (a.dcN) dc += a.dcN[(long long)rb * H + u0 + cunit];
-                    }
-                    const float tc = tanhf_(ct);
-                    dc += dh * og * (1.f - tc * tc);
-                    dp[0] = dc * gg * ig * (1.f - ig);
-                    dp[1] = dc * cp * fg * (1.f - fg);
-                    dp[2] = dc * ig * (1.f - gg * gg);
-                    dp[3] = dh * tc * og * (1.f - og);
-                    dc_next[mt] = dc * fg;
+            if (rb < a.B && t < len_r[mt]) {
+                const float ig = cur[mt].ig, fg = cur[mt].fg, gg = cur[mt].gg, og = cur[mt].og;
+                const float ct = ct_cur[mt], cp = cur[mt].cp;
+                float dh = dh_rec[mt] + cur[mt].dhs;
+                float dc = dc_next[mt];
+                if (t == len_r[mt] - 1) {
+                    if (a.dhN) dh += a.dhN[(long long)rb * H + u0 + cunit];
+                    if (a.dcN) dc += a.dcN[(long long)rb * H + u0 + cunit];
                 }
+                const float tc = tanhf_(ct);
+                dc += dh * og * (1.f - tc * tc);
+                dp[0] = dc * gg * ig * (1.f - ig);
+                dp[1] = dc * cp * fg * (1.f - fg);
+                dp[2] = dc * ig * (1.f - gg * gg);
+                dp[3] = dh * tc * og * (1.f - og);
+                dc_next[mt] = dc * fg;
             }
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt) { sA[mt][crow * 68 + gt * 16 + cunit] = dp[gt]; dpo[mt][gt] = dp[gt]; }
@@ -468,6 +486,8 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
                 pd[0] = dpo[mt][0]; pd[H] = dpo[mt][1]; pd[2 * H] = dpo[mt][2]; pd[3 * H] = dpo[mt][3];
             }
         }
+        StepIn nxt[MT];
+        load_step(t - 1, nxt);                   // in flight under the wait below
         if (tid == 0) s_ok = wait_ge(ctr, (unsigned)(a.NW * (s + 1)), tmo) ? 1 : 0;
         __syncthreads();
         if (!s_ok) break;
@@ -502,6 +522,8 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
             const int o = cunit * 20 + crow;
             dh_rec[mt] = (red[0][mt][o] + red[1][mt][o]) + (red[2][mt][o] + red[3][mt][o]);
         }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { ct_cur[mt] = cur[mt].cp; cur[mt] = nxt[mt]; }
         // the next iteration's barrier after (a) orders these LDS reads before red[] / sA[] are rewritten
     }
 

@@ -13,7 +13,8 @@ What is fused / restructured for MI355X (numerically equivalent within fp32 roun
     embedding matrix with the operator, whose reverse loop contracts them over the vocabulary
     inside the per-step Gumbel-softmax backward (a4nt_sgemm + a4nt_gumbel_bwd);
   * no host sync per step: `done` / `gen_lens` live on the device; the host looks at them every
-    CHECK_EVERY steps and once at the end (the reference syncs every step, :393).
+    CHECK_EVERY steps (reading the answer one period later, without draining the GPU) and once at the end (the
+    reference syncs every step, :393).
 """
 import torch
 from torch.autograd import Function
@@ -210,6 +211,7 @@ class _GenDecode(Function):
         tok0 = tok0.contiguous()
         s = ops._s()
         ran = 0
+        pending = None
         for t in range(n_max):
             tk = tok0 if t == 0 else tok[t - 1]
             vl = ones if t == 0 else val_in[t - 1]
@@ -225,8 +227,19 @@ class _GenDecode(Function):
                             cfg['tau'], cfg['hard'], greedy, ybuf[t] if need_grad else None, part,
                             stats[t], tok[t], val_in[t], val_out[t], gen_lens, done, cfg['end_c'], zrow0=r0)
             ran = t + 1
-            if cfg['end_c'] >= 0 and (ran % CHECK_EVERY == 0) and ran < n_max and bool(done.all()):
-                break
+            if cfg['end_c'] >= 0 and (ran % CHECK_EVERY == 0) and ran < n_max:
+                # "all sentences ended?" is read one period late: the answer asked for CHECK_EVERY steps ago has
+                # long arrived, so the host never waits for the GPU to drain (steps run past the end are trimmed
+                # below, as the steps between two checks already were)
+                if pending is not None:
+                    pending[0].synchronize()
+                    if bool(pending[1][0]):
+                        break
+                flag = torch.empty(1, dtype=torch.bool, pin_memory=True)
+                flag.copy_(done.all().view(1), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending = (ev, flag)
         n_out = int(gen_lens.max().item())          # = steps the reference loop would have run
         n_out = max(1, min(n_out, ran))
         if noise is not None and not greedy:

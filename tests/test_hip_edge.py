@@ -106,3 +106,34 @@ def test_generation_edge(B, lens, n_max, end_c):
     assert torch.equal(out['hip'][2], out['ref'][2]), 'generated lengths differ'
     assert_close(out['hip'][0], out['ref'][0], TOL_OUT, 'samples')
     assert_grads_close(hip.named_parameters(), _grads(ref), TOL_GRAD, 'generation edge')
+
+
+def test_generation_ends_long_before_n_max():
+    """Every sentence emits the end token within a few steps of a 60-step budget: the loop stops at one of its
+    periodic looks (one period late) and the outputs are trimmed to what the reference's per-step check gives."""
+    ref, hip, impl = _pair('CharTranslator', GP)
+    end_c = 7
+    with torch.no_grad():
+        for m in (ref, hip):
+            m.decoder_W.mul_(30.0)
+            m.decoder_b[end_c] += 2.0          # the end token wins early, not necessarily at once
+    B, lens, n_max = 5, [4, 3, 3, 2, 1], 60
+    inps = _ids(B, lens, 6)
+    auths = torch.arange(B) % 2
+    g = torch.Generator().manual_seed(10)
+    Vp = ref.decoder_W.shape[1]
+    noise = [torch.rand(B, Vp, generator=g) for _ in range(n_max)]
+    R = torch.randn(n_max, B, Vp, generator=g)
+    out = {}
+    for tag, m, dev in (('ref', ref, 'cpu'), ('hip', hip, 'cuda')):
+        m.set_noise([u.clone().to(dev) for u in noise])
+        s, gl, co = m.forward_advers_gen(inps, lens, soft_samples=True, temp=0.5, n_max=n_max, end_c=end_c, auths=auths)
+        samp = torch.stack(list(s), 0)
+        (samp * R[:samp.shape[0]].to(dev)).sum().backward()      # (a plain sum has a zero gradient: softmax rows sum to 1)
+        out[tag] = (samp.detach().cpu(), torch.stack(list(co), 0).cpu().long(), gl.cpu().long())
+    impl.check_timeouts()
+    assert int(out['ref'][2].max()) < 30, 'scenario no longer ends early: %s' % out['ref'][2]
+    assert out['hip'][0].shape == out['ref'][0].shape
+    assert torch.equal(out['hip'][1], out['ref'][1]) and torch.equal(out['hip'][2], out['ref'][2])
+    assert_close(out['hip'][0], out['ref'][0], TOL_OUT, 'samples')
+    assert_grads_close(hip.named_parameters(), _grads(ref), TOL_GRAD, 'early end')

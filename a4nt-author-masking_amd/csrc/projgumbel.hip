@@ -95,6 +95,9 @@ __device__ __forceinline__ void pg_mma(const PgBlock<RT>& blk, f32x4 (&acc)[RT][
 // RT = row tiles per wave: 1 up to 128 rows (one wave per SIMD); 2 above (256 rows: again 1008 waves, and
 // a B fragment now feeds two MFMAs, which keeps the CU's address pipe -- 4 waves x 9 loads per 16-k block --
 // below the matrix pipe's time; two waves per SIMD with RT = 1 measured 47 us against 2 x 25 us).
+// Also measured: two k-groups per workgroup (8 waves, each set of 4 on half of K, summed through LDS; same loads
+// and MFMAs per CU, two waves per SIMD): 47.2 against 47.9 us at 256 rows, 32.0 against 29.9 at 128 -- latency is
+// not what bounds this kernel, the per-lane unaligned B loads are.
 template <int RT>
 __global__ __launch_bounds__(256) void proj_gumbel_kernel(ProjGumbelArgs a) {
     constexpr int BM = 64 * RT;                              // rows per workgroup: wave w owns rows [16*RT*w, +16*RT)

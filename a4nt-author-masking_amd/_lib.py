@@ -52,6 +52,8 @@ _SIGS = {
     'a4nt_gumbel_fwd': (c_int, [c_int, c_int, P, c_int, P, c_int, c_ulonglong, c_uint, c_float, c_float, c_int, c_int,
                                 P, c_int, P, P, P, P, P, P, c_longlong, P, c_int, P]),
     'a4nt_gumbel_bwd': (c_int, [c_int, c_int, P, c_int, P, c_int, P, c_float, c_float, P, c_int, P]),
+    'a4nt_proj_gumbel_packed_floats': (c_longlong, [c_int, c_int]),
+    'a4nt_proj_gumbel_pack': (c_int, [c_int, c_int, P, c_int, P, P]),
     'a4nt_proj_gumbel_part_floats': (c_longlong, [c_int, c_int]),
     'a4nt_proj_gumbel_fwd': (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_float, c_float, c_int, c_int, P, c_int,
                                      c_ulonglong, c_uint, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_longlong, P]),

@@ -57,39 +57,49 @@ __device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-template <int RT>
+// PACKED: W comes as the image a4nt_proj_gumbel_pack writes once per generation: for every (strip, 16-k block) the
+// 20 B operands of each lane (4 k-steps x 5 column tiles) are contiguous, so a block is 5 aligned dwordx4 per lane
+// and 5 KB contiguous per wave, instead of 4 x (unaligned dwordx4 + dword) gathered at a 20-byte lane stride from
+// rows whose stride (V = 10001 floats) is not a multiple of 16 bytes -- the address pipe, not the matrix pipe, was
+// pacing the kernel.
+template <int RT, bool PACKED>
 struct PgBlock {            // operands of one 16-k block
     f32x4 a[RT];            // A: k-steps 0..3 of each of this wave's RT row tiles
-    f32x4 b4[4];            // B of k-step i: column tiles 0..3
-    float b1[4];            //                column tile 4
+    f32x4 b[5];             // B: element 5*i + c = k-step i, column tile c (unpacked: b[i] = tiles 0..3, b[4][i] = tile 4)
 };
 
-template <int RT>
-__device__ __forceinline__ void pg_load(PgBlock<RT>& blk, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
+template <int RT, bool PACKED>
+__device__ __forceinline__ void pg_load(PgBlock<RT, PACKED>& blk, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
                                         const unsigned (&aoff)[RT], unsigned boff, unsigned ldw_bytes, int kb, bool on) {
     // kb: first k of the block; `on` false (past the end of K) loads nothing that is used
 #pragma unroll
     for (int r = 0; r < RT; ++r) blk.a[r] = bl4(ra, on ? aoff[r] + (unsigned)kb * 4u : OOB);
+    if (PACKED) {
+        // boff = byte offset of this lane inside block 0 of its strip; blocks are 64 lanes x 80 bytes apart
+        const unsigned bo = on ? boff + (unsigned)(kb >> 4) * (64u * 80u) : OOB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned bo = on ? boff + (unsigned)(kb + i) * ldw_bytes : OOB;
-        blk.b4[i] = bl4(rb, bo);
-        blk.b1[i] = bl1(rb, on ? bo + 16u : OOB);
+        for (int v = 0; v < 5; ++v) blk.b[v] = bl4(rb, on ? bo + 16u * v : OOB);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned bo = on ? boff + (unsigned)(kb + i) * ldw_bytes : OOB;
+            blk.b[i] = bl4(rb, bo);
+            blk.b[4][i] = bl1(rb, on ? bo + 16u : OOB);
+        }
     }
 }
 
-template <int RT>
-__device__ __forceinline__ void pg_mma(const PgBlock<RT>& blk, f32x4 (&acc)[RT][5]) {
+template <int RT, bool PACKED>
+__device__ __forceinline__ void pg_mma(const PgBlock<RT, PACKED>& blk, f32x4 (&acc)[RT][5]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], blk.b4[i].x, acc[r][0], 0, 0, 0);
-            acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], blk.b4[i].y, acc[r][1], 0, 0, 0);
-            acc[r][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], blk.b4[i].z, acc[r][2], 0, 0, 0);
-            acc[r][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], blk.b4[i].w, acc[r][3], 0, 0, 0);
-            acc[r][4] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], blk.b1[i], acc[r][4], 0, 0, 0);
-        }
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const float bv = PACKED ? blk.b[(5 * i + c) >> 2][(5 * i + c) & 3] : (c < 4 ? blk.b[i][c] : blk.b[4][i]);
+                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(blk.a[r][i], bv, acc[r][c], 0, 0, 0);
+            }
 }
 
 // RT = row tiles per wave: 1 up to 128 rows (one wave per SIMD); 2 above (256 rows: again 1008 waves, and
@@ -98,27 +108,60 @@ __device__ __forceinline__ void pg_mma(const PgBlock<RT>& blk, f32x4 (&acc)[RT][
 // Also measured: two k-groups per workgroup (8 waves, each set of 4 on half of K, summed through LDS; same loads
 // and MFMAs per CU, two waves per SIMD): 47.2 against 47.9 us at 256 rows, 32.0 against 29.9 at 128 -- latency is
 // not what bounds this kernel, the per-lane unaligned B loads are.
-template <int RT>
-__global__ __launch_bounds__(256) void proj_gumbel_kernel(ProjGumbelArgs a) {
+// NW = 1: a second set of 4 waves ("noise waves") draws the Philox Gumbel noise of the four MFMA waves' tiles while
+// those multiply, and hands it over through LDS: with one wave per SIMD the noise (10 Philox calls and 80
+// logarithms per lane at RT = 2) ran after the k loop and cost 6.8 us of a 43 us launch; placed inside the k loop
+// of the same wave it cost the same (hipcc keeps it a block of its own between the MFMA blocks).  On a second wave
+// of the SIMD the hardware overlaps it with the MFMAs by itself.
+template <int RT, bool PACKED, int NW>
+__global__ __launch_bounds__(256 * (1 + NW)) void proj_gumbel_kernel(ProjGumbelArgs a) {
     constexpr int BM = 64 * RT;                              // rows per workgroup: wave w owns rows [16*RT*w, +16*RT)
     // 1-D grid; the row blocks of one strip sit 8 apart in block id (id % 8 = strip % 8), so under round-robin
     // placement they land on the same XCD and share the strip of W in that XCD's L2 (speed only)
     const int nrb = (a.M + BM - 1) / BM;
     const int grp = blockIdx.x / (8 * nrb), rem = blockIdx.x % (8 * nrb);
     const int strip = grp * 8 + (rem & 7), rblk = rem >> 3;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = NW ? (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3) : (int)(threadIdx.x >> 6);
+    const bool noise_wave = NW && __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0;
     const int fr = lane & 15, fq = lane >> 4;
     const int m0 = rblk * BM + 16 * RT * w, c0 = strip * PG_BC;
-    if (strip >= a.nstrips || m0 >= a.M) return;             // no barriers below
+    if (strip >= a.nstrips) return;                          // workgroup-uniform
+    const bool active = m0 < a.M;                            // wave-uniform
+    if (!NW && !active) return;                              // (with noise waves every wave reaches the barrier)
+    __shared__ __attribute__((aligned(16))) float sn[NW ? 4 * RT * 5 * 256 : 4];
+    if (noise_wave) {
+        if (active) {
+#pragma unroll
+            for (int t = 0; t < RT * 5; ++t) {
+                const int r = t / 5, c = t % 5;
+                unsigned o[4];        // one Philox4x32-10 call = the 4 rows (rbase..rbase+3) of this column
+                philox4x32((unsigned)(c0 + 5 * fr + c), (unsigned)((m0 + 16 * r + 4 * fq) >> 2), a.step, 0u,
+                           (unsigned)a.seed, (unsigned)(a.seed >> 32), o);
+                f32x4 gv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = (float)(o[e] >> 8) * (1.0f / 16777216.0f);
+                    gv[e] = -__logf(-__logf(u + 1e-20f) + 1e-20f);
+                }
+                *reinterpret_cast<f32x4*>(&sn[((w * RT * 5) + t) * 256 + 4 * lane]) = gv;
+            }
+        }
+        __syncthreads();
+        return;
+    }
 
     // A: rows m0+16r+fr (clamped), k offset 4*fq inside a block.  B: columns c0 + 5*fr .. +4, k row 4*fq + i.
     __amdgpu_buffer_rsrc_t ra = make_rsrc(a.h, clamp_bytes(((long long)(a.M - 1) * a.ldh + a.K) * 4));
-    __amdgpu_buffer_rsrc_t rb = make_rsrc(a.W, clamp_bytes(((long long)(a.K - 1) * a.ldw + a.N) * 4));
+    const int nkb = a.K >> 4;
+    __amdgpu_buffer_rsrc_t rb = PACKED ? make_rsrc(a.W, clamp_bytes((long long)a.nstrips * nkb * 64 * 80))
+                                       : make_rsrc(a.W, clamp_bytes(((long long)(a.K - 1) * a.ldw + a.N) * 4));
     unsigned aoff[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) aoff[r] = (unsigned)(min(m0 + 16 * r + fr, a.M - 1) * a.ldh + 4 * fq) * 4u;
     const unsigned ldw_bytes = (unsigned)a.ldw * 4u;
-    const unsigned boff = (unsigned)(4 * fq) * ldw_bytes + (unsigned)(c0 + 5 * fr) * 4u;
+    const unsigned boff = PACKED ? ((unsigned)strip * nkb * 64u + lane) * 80u
+                                 : (unsigned)(4 * fq) * ldw_bytes + (unsigned)(c0 + 5 * fr) * 4u;
 
     f32x4 acc[RT][5];
 #pragma unroll
@@ -126,16 +169,46 @@ __global__ __launch_bounds__(256) void proj_gumbel_kernel(ProjGumbelArgs a) {
 #pragma unroll
         for (int c = 0; c < 5; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nkb = a.K >> 4;
-    PgBlock<RT> ring[PG_DEPTH];
+    const bool philox = !a.greedy && !a.U;
+    constexpr int DEPTH = RT > 1 ? PG_DEPTH / 2 : PG_DEPTH;      // RT = 2: twice the MFMAs per block, half the ring
+    PgBlock<RT, PACKED> ring[DEPTH];
 #pragma unroll
-    for (int u = 0; u < PG_DEPTH; ++u) pg_load(ring[u], ra, rb, aoff, boff, ldw_bytes, 16 * u, u < nkb);
-    for (int j0 = 0; j0 < nkb; j0 += PG_DEPTH) {
+    for (int u = 0; u < DEPTH; ++u) pg_load(ring[u], ra, rb, aoff, boff, ldw_bytes, 16 * u, u < nkb);
+    for (int j0 = 0; j0 < nkb && active; j0 += DEPTH) {
 #pragma unroll
-        for (int u = 0; u < PG_DEPTH; ++u) {
+        for (int u = 0; u < DEPTH; ++u) {
             if (j0 + u < nkb) {                              // wave-uniform
                 pg_mma(ring[u], acc);
-                pg_load(ring[u], ra, rb, aoff, boff, ldw_bytes, 16 * (j0 + u + PG_DEPTH), j0 + u + PG_DEPTH < nkb);
+                pg_load(ring[u], ra, rb, aoff, boff, ldw_bytes, 16 * (j0 + u + DEPTH), j0 + u + DEPTH < nkb);
+            }
+        }
+    }
+    // Gumbel noise: from the noise waves (LDS), or drawn here
+    float gn[RT * 5][4];
+    if (NW) {
+        __syncthreads();
+        if (!active) return;
+#pragma unroll
+        for (int t = 0; t < RT * 5; ++t) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(&sn[((w * RT * 5) + t) * 256 + 4 * lane]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gn[t][e] = gv[e];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < RT * 5; ++t) {
+            const int r = t / 5, c = t % 5;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gn[t][e] = 0.f;
+            if (philox) {
+                unsigned o[4];
+                philox4x32((unsigned)(c0 + 5 * fr + c), (unsigned)((m0 + 16 * r + 4 * fq) >> 2), a.step, 0u,
+                           (unsigned)a.seed, (unsigned)(a.seed >> 32), o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = (float)(o[e] >> 8) * (1.0f / 16777216.0f);
+                    gn[t][e] = -__logf(-__logf(u + 1e-20f) + 1e-20f);
+                }
             }
         }
     }
@@ -150,24 +223,15 @@ __global__ __launch_bounds__(256) void proj_gumbel_kernel(ProjGumbelArgs a) {
         const int col = c0 + 5 * fr + c;
         const bool cvalid = col < a.N;
         const float bv = (a.bias && cvalid) ? a.bias[col] : 0.f;
-        float g4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!a.greedy) {
-            if (a.U) {
+        float g4[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = rbase + e;
-                    const float u = (row < a.M && cvalid) ? a.U[(long long)row * a.ldu + col] : 0.5f;
-                    g4[e] = -logf(-logf(u + 1e-20f) + 1e-20f);
-                }
-            } else {
-                // one Philox4x32-10 call = the 4 rows (rbase..rbase+3) of this column
-                unsigned o[4];
-                philox4x32((unsigned)col, (unsigned)(rbase >> 2), a.step, 0u, (unsigned)a.seed, (unsigned)(a.seed >> 32), o);
+        for (int e = 0; e < 4; ++e) g4[e] = gn[r * 5 + c][e];
+        if (!a.greedy && a.U) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float u = (float)(o[e] >> 8) * (1.0f / 16777216.0f);
-                    g4[e] = -__logf(-__logf(u + 1e-20f) + 1e-20f);
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int row = rbase + e;
+                const float u = (row < a.M && cvalid) ? a.U[(long long)row * a.ldu + col] : 0.5f;
+                g4[e] = -logf(-logf(u + 1e-20f) + 1e-20f);
             }
         }
 #pragma unroll
@@ -256,6 +320,34 @@ __global__ __launch_bounds__(64) void proj_gumbel_final_kernel(PgFinalArgs a) {
     }
 }
 
+// Packed image of W [K][N] for proj_gumbel_kernel<.., true>: float ((strip*nkb + kb)*64 + lane)*20 + 5*i + c
+// = W[16*kb + 4*(lane>>4) + i][80*strip + 5*(lane&15) + c] (0 past the last column).
+__global__ __launch_bounds__(64) void proj_gumbel_pack_kernel(int K, int N, const float* W, int ldw, float* Wp, int nkb) {
+    const int strip = blockIdx.x / nkb, kb = blockIdx.x % nkb, lane = threadIdx.x;
+    const int fr = lane & 15, fq = lane >> 4;
+    float* dst = Wp + ((long long)blockIdx.x * 64 + lane) * 20;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int k = 16 * kb + 4 * fq + i, col = PG_BC * strip + 5 * fr + c;
+            dst[5 * i + c] = (k < K && col < N) ? W[(long long)k * ldw + col] : 0.f;
+        }
+}
+extern "C" long long a4nt_proj_gumbel_packed_floats(int K, int N) {
+    if (K <= 0 || N <= 0 || (K & 15)) return 0;
+    return (long long)((N + PG_BC - 1) / PG_BC) * (K >> 4) * 64 * 20;
+}
+extern "C" int a4nt_proj_gumbel_pack(int K, int N, const float* W, int ldw, float* Wp, void* stream) {
+    if (K <= 0 || N <= 0 || (K & 15) || !W || !Wp || ldw < N || (reinterpret_cast<uintptr_t>(Wp) & 15)) {
+        a4nt_set_error("a4nt_proj_gumbel_pack: bad arguments (K=%d must be a multiple of 16, N=%d, ldw=%d)", K, N, ldw);
+        return A4NT_ERR_ARG;
+    }
+    const int nkb = K >> 4, nstrips = (N + PG_BC - 1) / PG_BC;
+    hipLaunchKernelGGL(proj_gumbel_pack_kernel, dim3(nstrips * nkb), dim3(64), 0, (hipStream_t)stream, K, N, W, ldw, Wp, nkb);
+    return a4nt_check_launch("proj_gumbel_pack");
+}
+
 extern "C" long long a4nt_proj_gumbel_part_floats(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
     return (long long)M * ((N + PG_BC - 1) / PG_BC) * 4;
@@ -282,8 +374,14 @@ extern "C" int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh
     const int nrb = (M + 64 * rt - 1) / (64 * rt);
     dim3 grid(((a.nstrips + 7) / 8) * 8 * nrb), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (rt == 1) hipLaunchKernelGGL(proj_gumbel_kernel<1>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(proj_gumbel_kernel<2>, grid, block, 0, s, a);
+    const bool packed = ldw == 0;                   // W is the image written by a4nt_proj_gumbel_pack
+    if (packed && (reinterpret_cast<uintptr_t>(W) & 15)) { a4nt_set_error("a4nt_proj_gumbel_fwd: packed W must be 16-byte aligned"); return A4NT_ERR_ARG; }
+    const bool nw = !greedy && !U;                  // Philox noise: drawn by a second set of waves
+    if (nw) block = dim3(512);
+#define PG_LAUNCH(RT_, PK_, NW_) hipLaunchKernelGGL((proj_gumbel_kernel<RT_, PK_, NW_>), grid, block, 0, s, a)
+    if (rt == 1) { if (packed) { if (nw) PG_LAUNCH(1, true, 1); else PG_LAUNCH(1, true, 0); } else { if (nw) PG_LAUNCH(1, false, 1); else PG_LAUNCH(1, false, 0); } }
+    else         { if (packed) { if (nw) PG_LAUNCH(2, true, 1); else PG_LAUNCH(2, true, 0); } else { if (nw) PG_LAUNCH(2, false, 1); else PG_LAUNCH(2, false, 0); } }
+#undef PG_LAUNCH
     int rc = a4nt_check_launch("proj_gumbel");
     if (rc != A4NT_OK) return rc;
     PgFinalArgs f;

@@ -23,6 +23,7 @@ from . import ops
 from .ops import gemm, gemm_auto, slab_reduce, colsum, embed_fwd, embed_bwd
 
 CHECK_EVERY = 16
+PACK_W = True             # re-lay the output projection out for the fused kernel once per generation
 
 
 class _GenHandle(object):
@@ -207,6 +208,8 @@ class _GenDecode(Function):
         gen_lens = torch.zeros(B, dtype=torch.int32, device=dev)
         done = torch.zeros(B, dtype=torch.uint8, device=dev)
         part = torch.empty(int(lib.a4nt_proj_gumbel_part_floats(B, V)), device=dev)
+        # the projection matrix re-laid out for the fused kernel's loads, once for all n_max steps
+        W_packed = ops.proj_gumbel_pack(W_out) if (PACK_W and n_max >= 4 and H % 16 == 0) else None
         ones = torch.ones(B, device=dev)
         tok0 = tok0.contiguous()
         s = ops._s()
@@ -225,7 +228,8 @@ class _GenDecode(Function):
                 assert tuple(U.shape) == (B, V)
             ops.proj_gumbel(hs_all[t + 1], W_out, b_out, U, cfg.get('seed', 0), cfg.get('step0', 0) + t, cfg['scale'],
                             cfg['tau'], cfg['hard'], greedy, ybuf[t] if need_grad else None, part,
-                            stats[t], tok[t], val_in[t], val_out[t], gen_lens, done, cfg['end_c'], zrow0=r0)
+                            stats[t], tok[t], val_in[t], val_out[t], gen_lens, done, cfg['end_c'], zrow0=r0,
+                            packed=W_packed)
             ran = t + 1
             if cfg['end_c'] >= 0 and (ran % CHECK_EVERY == 0) and ran < n_max:
                 # "all sentences ended?" is read one period late: the answer asked for CHECK_EVERY steps ago has

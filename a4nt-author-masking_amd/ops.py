@@ -769,15 +769,27 @@ def gumbel_bwd_rows(ds, y, stats, coef, inv_tau=1.0, out=None):
                               _ld(out), _s()), 'a4nt_gumbel_bwd')
 
 
+def proj_gumbel_pack(W):
+    """Packed image of the [K,N] projection matrix for proj_gumbel(packed=...): one pass over W, made once per
+    generation."""
+    lib = _lib.load()
+    W = _rowmajor(_f32(W, 'proj_gumbel_pack W'))
+    K, N = W.shape
+    Wp = torch.empty(int(lib.a4nt_proj_gumbel_packed_floats(K, N)), device=W.device, dtype=torch.float32)
+    check(lib.a4nt_proj_gumbel_pack(K, N, _p(W), _ld(W), _p(Wp), _s()), 'a4nt_proj_gumbel_pack')
+    return Wp
+
+
 def proj_gumbel(h, W, bias, U, seed, step, scale, tau, hard, greedy, z, part, stats, tok, val_in, val_out, gen_lens,
-                done, end_c, zrow0=0):
+                done, end_c, zrow0=0, packed=None):
     """Fused decoder-step projection + Gumbel-softmax sampling (a4nt_proj_gumbel_fwd).
-    z (optional) receives rows [zrow0, zrow0 + z.shape[0]) of the batch."""
+    z (optional) receives rows [zrow0, zrow0 + z.shape[0]) of the batch.  packed: W's image from proj_gumbel_pack
+    (W is then only used for its shape)."""
     lib = _lib.load()
     M, K = h.shape
     N = W.shape[1]
     with _Timed('proj_gumbel', 2.0 * M * N * K):
-        check(lib.a4nt_proj_gumbel_fwd(M, N, K, _p(h), _ld(h), _p(W), _ld(W), _p(bias), float(scale), float(tau),
+        check(lib.a4nt_proj_gumbel_fwd(M, N, K, _p(h), _ld(h), _p(W if packed is None else packed), _ld(W) if packed is None else 0, _p(bias), float(scale), float(tau),
                                        int(hard), int(greedy), _p(U), _ld(U) if U is not None else 0, int(seed),
                                        int(step), _p(z), _ld(z) if z is not None else 0, int(zrow0),
                                        int(z.shape[0]) if z is not None else 0, _p(part), _p(stats), _p(tok),

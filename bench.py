@@ -190,6 +190,7 @@ def main():
                     help='kernel timed with HIP events inside the timed region (default: the kernel with the '
                          'largest share of the step in profiles/: sgemm_kernel<false,true,2,2,2>)')
     ap.add_argument('--no-extra-rooflines', action='store_true')
+    ap.add_argument('--no-pack-w', action='store_true', help='fused projection reads the [H,V] matrix as stored')
     ap.add_argument('--lstm-workgroups', type=int, default=0, choices=(0, 256, 512),
                     help='persistent LSTM sweep residency (0: 512 on one GPU, 256 beside RCCL kernels when N > 1)')
     args = ap.parse_args()
@@ -206,6 +207,9 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     import a4nt_amd as impl
     from a4nt_amd import ops
+    if args.no_pack_w:
+        from a4nt_amd import gen_decode
+        gen_decode.PACK_W = False
     if args.lstm_workgroups:
         impl.lstm_set_max_workgroups(args.lstm_workgroups)
     elif world > 1:

@@ -166,6 +166,12 @@ int a4nt_gumbel_bwd(int B, int V, const float* ds, int ldd, const float* y, int 
  * a4nt_gumbel_bwd(inv_tau = 1/tau) (may be NULL); part is scratch of a4nt_proj_gumbel_part_floats().
  * Replaces: dec_out = p_rnn.mm(W)+b; gumbel_softmax_sample(dec_out*scale, tau); argmax; done/len
  * updates (char_translator.py:377-392) -- softmax((log_softmax(x)+g)/tau) == softmax((x+g)/tau). */
+/* W may be given as the packed image a4nt_proj_gumbel_pack writes (pass ldw = 0): per (80-column strip, 16-k block)
+ * the B operands of every lane are contiguous, so the kernel reads 5 aligned 16-byte words per lane and block
+ * instead of gathering 20-byte pieces from rows whose stride is not a multiple of 16 bytes.  Pack once per
+ * generation (the weights do not change inside it); a4nt_proj_gumbel_packed_floats gives the image size. */
+long long a4nt_proj_gumbel_packed_floats(int K, int N);
+int a4nt_proj_gumbel_pack(int K, int N, const float* W, int ldw, float* Wp, void* stream);
 long long a4nt_proj_gumbel_part_floats(int M, int N);
 int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh, const float* W, int ldw, const float* bias,
                          float scale, float tau, int hard, int greedy, const float* U, int ldu,

@@ -398,6 +398,13 @@ def test_proj_gumbel_fused(ops, M, N, K, greedy):
                     stats, tok, val_in, val_out, lens, done, end_c)
     assert torch.equal(tok.cpu(), tok_r), 'tokens differ'
     assert_close(z, zr.float(), 2e-6, 'z')
+    # the packed image of W gives the same launch bit for bit (same products in the same order)
+    z2, stats2, tok2 = torch.zeros_like(z), torch.zeros_like(stats), torch.zeros_like(tok)
+    ops.proj_gumbel(h.cuda(), W.cuda(), b.cuda(), None if greedy else U.cuda(), 0, 0, scale, tau, 1, greedy, z2, part,
+                    stats2, tok2, torch.zeros(M, device=dev), torch.zeros(M, device=dev),
+                    torch.zeros(M, dtype=torch.int32, device=dev), torch.zeros(M, dtype=torch.uint8, device=dev), end_c,
+                    packed=ops.proj_gumbel_pack(W.cuda()))
+    assert torch.equal(z2, z) and torch.equal(stats2, stats) and torch.equal(tok2, tok)
     assert_close(stats[:, 0], zr.max(1)[0].float(), 2e-6, 'max z')
     if not greedy:
         # exp((z - max)/tau) amplifies the fp32 rounding of z (|z| ~ 40, 1/tau = 2): conditioning, not the kernel
@@ -425,5 +432,34 @@ def test_proj_gumbel_philox(ops):
         toks.append(tok.cpu())
         counts += torch.bincount(tok.cpu(), minlength=N).float()
     assert not torch.equal(toks[0], toks[1])
+    # the noise drawn by the second set of waves is the documented stream: z = scale*(hW) - log(-log(u)), u = 24 high
+    # bits of Philox4x32-10 with counter (column, row/4, step, 0) and key = seed, output word row%4
+    import numpy as np
+
+    def philox(c0, c1, c2, k0, k1):
+        c = [c0.astype(np.uint64), c1.astype(np.uint64), np.full_like(c0, c2, dtype=np.uint64), np.zeros_like(c0, dtype=np.uint64)]
+        k0, k1 = np.uint64(k0), np.uint64(k1)
+        m32 = np.uint64(0xFFFFFFFF)
+        for _ in range(10):
+            p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+            c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+            k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+        return c
+
+    M2, N2, K2, seed, step = 70, 333, 32, 77 + (5 << 32), 5
+    h2, W2 = _rand(M2, K2, seed=3).cuda(), _rand(K2, N2, seed=4).cuda()
+    cols, rows = np.meshgrid(np.arange(N2), np.arange(M2))
+    o = philox(cols, rows >> 2, step, seed & 0xFFFFFFFF, seed >> 32)
+    word = np.choose(rows & 3, o)
+    u = (word >> np.uint64(8)).astype(np.float64) / 16777216.0
+    zr = 3.0 * (h2.double() @ W2.double()).cpu() + torch.from_numpy(-np.log(-np.log(u + 1e-20) + 1e-20))
+    for packed in (None, ops.proj_gumbel_pack(W2)):
+        z = torch.zeros(M2, N2).cuda()
+        part2 = torch.empty(int(lib.a4nt_proj_gumbel_part_floats(M2, N2))).cuda()
+        tok = torch.zeros(M2, dtype=torch.int64).cuda()
+        ops.proj_gumbel(h2, W2, None, None, seed, step, 3.0, 0.5, 1, 0, z, part2, None, tok, None, None, None, None, -1,
+                        packed=packed)
+        assert_close(z, zr.float(), 1e-5, 'z with Philox noise')
+        assert torch.equal(tok.cpu(), zr.argmax(1))
     expected = M * 60 / N
     assert counts.min() > 0.55 * expected and counts.max() < 1.45 * expected

@@ -203,6 +203,10 @@ def _auto_ksplit(M, N, K):
     for ks in range(1, int(min(16, K // 512)) + 1):
         rounds = (t128 * ks + 255) // 256
         t = rounds * (0.06875 * ((K + ks - 1) // ks) + 4.0)                 # us
+        # one workgroup per CU is one wave per SIMD: its load / barrier waits show (measured on the 64-tile
+        # [2048 x 512] weight gradients: 280 us with 256 workgroups, 240 us with 512 or 768)
+        wgs_per_cu = t128 * ks / 256.0
+        t /= 0.85 if wgs_per_cu < 1.5 else 1.0
         if ks > 1:
             t += (2 * ks + 1) * M * N * 4 / 3.5e6 + 6.0                     # slab write + reduce pass
         if best_t is None or t < 0.97 * best_t:

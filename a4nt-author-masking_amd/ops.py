@@ -208,7 +208,10 @@ def _auto_ksplit(M, N, K):
         wgs_per_cu = t128 * ks / 256.0
         t /= 0.85 if wgs_per_cu < 1.5 else 1.0
         if ks > 1:
-            t += (2 * ks + 1) * M * N * 4 / 3.5e6 + 6.0                     # slab write + reduce pass
+            # slab write + reduce pass: slabs that fit the Infinity Cache cost about a third of HBM-sized ones
+            # ([2048 x 512] x 16 slabs: +3 us over 8 slabs; [512 x 10001]: +42 us from 4 to 8 slabs)
+            bw = 3.5e6 if ks * M * N * 4 > 96e6 else 1.0e7
+            t += (2 * ks + 1) * M * N * 4 / bw + 6.0
         if best_t is None or t < 0.97 * best_t:
             best, best_t = ks, t
     return best
@@ -506,7 +509,7 @@ class _LstmLayer(Function):
         dgates, dh0, dc0 = lstm_seq_bwd(w_hh.contiguous(), gates, cs, c0 if has_c0 else None,
                                         lens_dev if has_lens else None, dout, dhN, dcN, need_h0)
         dG2 = dgates.view(T * B, 4 * H)
-        dx = gemm(dG2, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
+        dx = gemm_auto(dG2, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = gemm_auto(dG2, x2, transA=True) if ctx.needs_input_grad[1] else None
         dw_hh = gemm_auto(dG2, hs_all[:T].view(T * B, H), transA=True) if ctx.needs_input_grad[2] else None
         db = colsum(dG2) if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
@@ -584,7 +587,7 @@ class _LstmLayerPair(Function):
             dgates, dh0, dc0 = res[k]
             x2, w_ih, hs_all, T, B, I, H, has_c0, has_gc, has_h0, nig = info[k]
             dG2 = dgates.view(T * B, 4 * H)
-            dx = gemm(dG2, w_ih).view(T, B, I) if nig[0] else None
+            dx = gemm_auto(dG2, w_ih).view(T, B, I) if nig[0] else None
             dw_ih = gemm_auto(dG2, x2, transA=True) if nig[1] else None
             dw_hh = gemm_auto(dG2, hs_all[:T].view(T * B, H), transA=True) if nig[2] else None
             db = colsum(dG2) if (nig[3] or nig[4]) else None

@@ -7,7 +7,7 @@ FLAGS="-O3 -std=c++17 --offload-arch=$ARCH -fPIC -fno-gpu-rdc -Wno-unused-result
 OBJS=""
 pids=()
 for f in capi sgemm skinny ntrows lstm rows misc projgumbel; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ gemm_stage.h -nt $f.o ]; then
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ gemm_stage.h -nt $f.o ] || [ ../../include/a4nt_hip.h -nt $f.o ]; then
     hipcc $FLAGS -c $f.hip -o $f.o &
     pids+=($!)
   fi

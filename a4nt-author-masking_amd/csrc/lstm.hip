@@ -684,17 +684,7 @@ extern "C" int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const fl
 // ---------------------------------------------------------------------------------------------
 // two sweeps in one launch
 // ---------------------------------------------------------------------------------------------
-struct a4nt_lstm_fwd_problem {      // mirrors include/a4nt_hip.h
-    int T, B;
-    const float* gx; const float* gc; const float* whh; const float* h0; const float* c0; const int* lens;
-    float* hs; float* gates; float* cs; float* hN; float* cN; float* xch; unsigned* sync;
-};
-struct a4nt_lstm_bwd_problem {
-    int T, B;
-    const float* whh; const float* gates; const float* cs; const float* c0; const int* lens;
-    const float* dhs; const float* dhN; const float* dcN;
-    float* dgates; float* dh0; float* dc0; float* xch; unsigned* sync;
-};
+// (a4nt_lstm_fwd_problem / a4nt_lstm_bwd_problem: include/a4nt_hip.h)
 
 #define A4NT_DISPATCH_LSTM2(KERNEL, mt, nj, grid, block, s, a, b, nA)                                             \
     do {                                                                                                         \

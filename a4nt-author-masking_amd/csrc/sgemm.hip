@@ -118,8 +118,24 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
     float (*As)[ASZ] = reinterpret_cast<float (*)[ASZ]>(smem + grp * 2 * (ASZ + BSZ));
     float (*Bs)[BSZ] = reinterpret_cast<float (*)[BSZ]>(smem + grp * 2 * (ASZ + BSZ) + 2 * ASZ);
 
-    const int tile = blockIdx.x;
-    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    // Tile order.  Workgroups are dealt to the 8 XCDs round robin (block b -> XCD b % 8; speed only, nothing depends
+    // on it), and each XCD has its own 4 MB L2: XCD x takes a contiguous eighth of a banded tile order (bands of 8
+    // tile columns, row-major inside a band), so the ~96 tiles an XCD runs at a time share about 12 A row panels and
+    // 8 B column panels (5 MB at K = 512) instead of 48 + 2 spread over the whole matrix.
+    int tile = blockIdx.x;
+    {
+        const int nt = gridDim.x, x = tile & 7, i = tile >> 3;
+        tile = x * (nt >> 3) + min(x, nt & 7) + i;
+    }
+    int tm, tn;
+    {
+        const int tiles_m = gridDim.x / g.tiles_n;
+        const int band_tiles = tiles_m * 8, band = tile / band_tiles;
+        const int wb = min(8, g.tiles_n - 8 * band);            // width of this band
+        const int idx = tile - band * band_tiles;
+        tm = idx / wb;
+        tn = 8 * band + idx % wb;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int wg_kbeg = blockIdx.z * g.kchunk;
     const int wg_kend = min(g.K, wg_kbeg + g.kchunk);

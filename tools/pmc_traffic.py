@@ -21,7 +21,10 @@ import sys
 from collections import defaultdict
 
 LABELS = [
-    (r'sgemm_kernel<(true|false), (true|false), (\d), \d, \d>', None),
+    (r'sgemm_kernel<(true|false), (true|false), (\d), \d, \d(?:, \d)?>', None),
+    (r'lstm_fwd2_kernel', 'lstm_seq_fwd_pair'),
+    (r'lstm_bwd2_kernel', 'lstm_seq_bwd_pair'),
+    (r'nt_rows_kernel', 'sgemm_nt_rows'),
     (r'lstm_fwd_kernel', 'lstm_fwd_kernel'),
     (r'lstm_bwd_kernel', 'lstm_seq_bwd'),
     (r'proj_gumbel_kernel', 'proj_gumbel'),

@@ -251,6 +251,8 @@ static int launch_small(GemmArgs g, int ksplit, hipStream_t s) {
     }
 }
 
+static thread_local bool g_tail_split = true;
+
 extern "C" int a4nt_sgemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                           int ldb, float* C, int ldc, const float* bias, int beta, int ksplit, long long slab_stride,
                           void* stream) {
@@ -262,6 +264,26 @@ extern "C" int a4nt_sgemm(int transA, int transB, int M, int N, int K, const flo
     if (ksplit > 1 && (beta || slab_stride < (long long)M * ldc)) {
         a4nt_set_error("a4nt_sgemm: split-K needs beta=0 and slab_stride >= M*ldc");
         return A4NT_ERR_ARG;
+    }
+    // Tail split: a launch of t 128x128 tiles takes ceil(t/256) rounds on the 256 CUs; when the last round would be
+    // mostly empty (1600 tiles = 6.25 rounds for [12800 x 2048], 800 = 3.125 for [25600 x 512]) the rows of that
+    // partial round go to a second launch, which then runs 64x64 tiles on every CU.
+    if (ksplit == 1 && g_tail_split) {
+        const long long tn = (N + 127) / 128, tm = (M + 127) / 128, t = tm * tn;
+        const long long rem = t % 256;
+        if (t > 256 && rem > 0 && rem <= 80) {
+            const long long rows_tail = (rem + tn - 1) / tn;                 // tile rows of the partial round
+            const long long m1 = (tm - rows_tail) * 128;
+            if (m1 > 0 && (tm - rows_tail) * tn >= 256 && rows_tail * tn <= 96) {
+                const float* A2 = transA ? A + m1 : A + m1 * (long long)lda;
+                g_tail_split = false;                                        // (the two halves are not split again)
+                int rc = a4nt_sgemm(transA, transB, (int)m1, N, K, A, lda, B, ldb, C, ldc, bias, beta, 1, 0, stream);
+                if (rc == A4NT_OK)
+                    rc = a4nt_sgemm(transA, transB, M - (int)m1, N, K, A2, lda, B, ldb, C + m1 * (long long)ldc, ldc, bias, beta, 1, 0, stream);
+                g_tail_split = true;
+                return rc;
+            }
+        }
     }
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias;

@@ -121,6 +121,21 @@ def test_sgemm_kgroups(ops, kg):
     assert lib.a4nt_sgemm_set_kgroups(3) != 0
 
 
+@pytest.mark.parametrize('M,N,K,tA,tB', [(12800, 2048, 48, 0, 1), (25600, 512, 40, 0, 0), (6528, 1024, 33, 1, 0)])
+def test_sgemm_tail_split(ops, M, N, K, tA, tB):
+    """Tile counts just above a multiple of 256 (1600, 800, 408): the rows of the partial last round run as a second
+    launch; bias and accumulation apply to both parts."""
+    A = _rand(K, M, seed=71) if tA else _rand(M, K, seed=71)
+    B = _rand(N, K, seed=72) if tB else _rand(K, N, seed=72)
+    bias, C0 = _rand(N, seed=73), _rand(M, N, seed=74)
+    ref = (A.t() if tA else A).double() @ (B.t() if tB else B).double()
+    out = ops.gemm(A.cuda(), B.cuda(), bool(tA), bool(tB), bias=bias.cuda())
+    assert_close(out, (ref + bias.double()).float(), 2e-6, 'tail split')
+    acc = C0.cuda()
+    ops.gemm(A.cuda(), B.cuda(), bool(tA), bool(tB), out=acc, beta=1)
+    assert_close(acc, (ref + C0.double()).float(), 2e-6, 'tail split beta=1')
+
+
 def test_sgemm_splitk(ops):
     A, B = _rand(128, 10001, seed=5), _rand(512, 10001, seed=6)
     ref = A.double() @ B.double().t()

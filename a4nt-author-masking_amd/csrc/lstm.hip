@@ -399,8 +399,10 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
     }
 
     int s = 0;   // published steps so far
+    STAMP_DECL
     for (int t = Tg - 1; t >= 0; --t, ++s) {
         const int par = s & 1;
+        STAMP_BEGIN();
         float dpo[MT][4];
         // (a) cell backward for this thread's (row, unit)
 #pragma unroll
@@ -440,6 +442,7 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
             break;
         }
         __syncthreads();
+        STAMP(0);
         // (b) partial dh_{t-1}[:, this wave's columns] = dgates_t[:, own 64] * W_hh[own 64 rows, those columns]
         // column tiles go CHB at a time (bounds the accumulator registers at H = 1024 / MT = 4); the A
         // fragments are re-read from LDS per gate and chunk
@@ -474,9 +477,11 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
                     st16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + 4 * fq) * 4), acc[c8][mt]);
                 }
         }
+        STAMP(1);
         drain_vmem();
         __syncthreads();
         if (tid == 0) add_flag(ctr, 1u);
+        STAMP(2);
         // dgates_t for the time-batched weight-gradient GEMMs: nobody waits for it inside this launch
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -488,9 +493,11 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
         }
         StepIn nxt[MT];
         load_step(t - 1, nxt);                   // in flight under the wait below
+        STAMP(3);
         if (tid == 0) s_ok = wait_ge(ctr, (unsigned)(a.NW * (s + 1)), tmo) ? 1 : 0;
         __syncthreads();
         if (!s_ok) break;
+        STAMP(4);
         // (c) sum the NW partial blocks of this workgroup's 16 columns: wave w takes producers [w*NJ, (w+1)*NJ)
         f32x4 ps[MT];
 #pragma unroll
@@ -512,6 +519,8 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
                     ps[mt].x += ld[p8][mt].x; ps[mt].y += ld[p8][mt].y; ps[mt].z += ld[p8][mt].z; ps[mt].w += ld[p8][mt].w;
                 }
         }
+        STAMP_WAITV();
+        STAMP(5);
         // lane l holds column l>>2, rows 4*(l&3)..+3
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -524,9 +533,11 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { ct_cur[mt] = cur[mt].cp; cur[mt] = nxt[mt]; }
+        STAMP(6);
         // the next iteration's barrier after (a) orders these LDS reads before red[] / sA[] are rewritten
     }
 
+    STAMP_FLUSH(a.sync, a.G);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int rb = r0 + 16 * mt + crow;

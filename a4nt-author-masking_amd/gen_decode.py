@@ -287,8 +287,13 @@ class _GenDecode(Function):
         S2 = ops.padded_rows(n * B, V, dev)             # rows 16-byte aligned for the time-batched GEMMs
         S = S2.unflatten(0, (n, B))
         first = True
-        for demb, W in handle.contribs:
-            gemm(demb[:n].reshape(n * B, -1), W, transB=True, out=S2, beta=0 if first else 1)
+        contribs = [(demb[:n].reshape(n * B, -1), W) for demb, W in handle.contribs]
+        if len(contribs) > 1 and all(W.shape[0] == V for _, W in contribs):
+            # sum_i demb_i W_i^T = [demb_1 | demb_2 | ..] [W_1 | W_2 | ..]^T: one product over the concatenated
+            # embedding dimensions instead of one per consumer, each re-reading and re-writing the [n*B, V] buffer
+            contribs = [(torch.cat([d for d, _ in contribs], dim=1), torch.cat([W for _, W in contribs], dim=1))]
+        for demb2, W in contribs:
+            gemm(demb2, W, transB=True, out=S2, beta=0 if first else 1)
             first = False
         for dd in handle.dense_grads:
             if first:

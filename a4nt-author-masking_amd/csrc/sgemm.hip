@@ -16,7 +16,9 @@
 // a CU that holds one tile (the single-group kernel was latency bound there) without more C slabs.
 #include "common.h"
 
-#define BK 16
+#ifndef BK
+#define BK 16  // 32 was measured: two workgroups per CU instead of three, 113 against 124 TFLOP/s on the K = 512 shapes
+#endif
 #ifndef PFB
 #define PFB 2   // K tiles in flight, 128x128 tiles
 #endif

@@ -50,16 +50,32 @@ extern "C" int a4nt_embed_bwd(long long N, int E, int V, const long long* ids, c
 
 // out[n] (+)= sum_m A[m][n]
 __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* A, int lda, float* out, int rows_per) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int w = threadIdx.x >> 6;
+    // one workgroup = 256 columns x rows_per rows: lane l of every wave owns columns 4l..4l+3 of the block (one 16-byte
+    // load per row when the row is 16-byte aligned, 1 KB per wave instruction), the 4 waves take every 4th row
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + 4 * lane;
     const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
-    float s = 0.f;
-    if (c < N)
-        for (int m = m0 + w; m < m1; m += 4) s += A[(long long)m * lda + c];
-    red[w][threadIdx.x & 63] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const bool vec = (c + 3 < N) && ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    if (vec) {
+        for (int m = m0 + w; m < m1; m += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(A + (long long)m * lda + c);
+            s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        }
+    } else if (c < N) {
+        for (int m = m0 + w; m < m1; m += 4) {
+            const float* p = A + (long long)m * lda + c;
+            s0 += p[0];
+            if (c + 1 < N) s1 += p[1];
+            if (c + 2 < N) s2 += p[2];
+            if (c + 3 < N) s3 += p[3];
+        }
+    }
+    red[w][4 * lane] = s0; red[w][4 * lane + 1] = s1; red[w][4 * lane + 2] = s2; red[w][4 * lane + 3] = s3;
     __syncthreads();
-    if (w == 0 && c < N) atomicAdd(&out[c], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < N) atomicAdd(&out[cc], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 extern "C" int a4nt_colsum(int M, int N, const float* A, int lda, float* out, int accumulate, void* stream) {
     if (N <= 0) return A4NT_OK;
@@ -67,8 +83,8 @@ extern "C" int a4nt_colsum(int M, int N, const float* A, int lda, float* out, in
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * 4, s) != hipSuccess) return a4nt_check_launch("colsum memset");
     if (M == 0) return A4NT_OK;
-    const int cb = (N + 63) / 64;
-    int chunks = max(1, min((M + 63) / 64, 2048 / cb));
+    const int cb = (N + 255) / 256;
+    int chunks = max(1, min((M + 31) / 32, 2048 / cb));
     const int rows_per = (M + chunks - 1) / chunks;
     chunks = (M + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(colsum_kernel, dim3(cb, chunks), dim3(256), 0, s, M, N, A, lda, out, rows_per);

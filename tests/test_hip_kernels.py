@@ -151,6 +151,11 @@ def test_sgemm_splitk(ops):
 def test_colsum_embed(ops):
     A = _rand(1000, 333, seed=8)
     assert_close(ops.colsum(A.cuda()), A.double().sum(0).float(), 2e-6, 'colsum')
+    for (M, N) in [(1200, 2048), (37, 260), (5, 3), (700, 10016)]:      # 16-byte aligned rows: vector loads; ragged edge block
+        A2 = _rand(M, N, seed=M + N)
+        assert_close(ops.colsum(A2.cuda()), A2.double().sum(0).float(), 2e-6, 'colsum %dx%d' % (M, N))
+        wide = _rand(M, N + 8, seed=M).cuda()
+        assert_close(ops.colsum(wide[:, 4:N + 4]), wide[:, 4:N + 4].double().sum(0).float().cpu(), 2e-6, 'colsum view')
     W = _rand(51, 24, seed=9)
     ids = torch.randint(0, 51, (7, 5), generator=torch.Generator().manual_seed(1))
     sc = _rand(7, 5, seed=10)

@@ -37,6 +37,7 @@ _SIGS = {
     'a4nt_sgemm_skinny': (c_int, [c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_longlong, P]),
     'a4nt_lstm_geometry': (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     'a4nt_lstm_set_max_workgroups': (c_int, [c_int]),
+    'a4nt_lstm_resident_workgroups': (c_int, [c_int, c_int, c_int]),
     'a4nt_lstm_xch_floats': (c_longlong, [c_int, c_int, c_int]),
     'a4nt_lstm_sync_words': (c_int, [c_int, c_int]),
     'a4nt_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),

@@ -42,7 +42,13 @@ extern "C" int a4nt_init(int device, int* num_cus) {
         a4nt_set_error("a4nt_init: device %d exposes %d CUs; the persistent LSTM sweeps need 256 co-resident workgroups", device, p.multiProcessorCount);
         return A4NT_ERR_ARG;
     }
-    return A4NT_OK;
+    // every workgroup of a persistent sweep must be resident at once: record what the occupancy calculator says
+    // about each instantiation (needs `device` current for the query)
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) return a4nt_check_launch("a4nt_init set device");
+    const int rc = a4nt_lstm_probe_occupancy(device, p.multiProcessorCount);
+    (void)hipSetDevice(prev);
+    return rc;
 }
 
 // Reads the timeout word a persistent sweep raises when a bounded inter-workgroup wait expired.
@@ -52,7 +58,8 @@ extern "C" int a4nt_lstm_check_timeout(const unsigned* sync, int groups, void* s
     unsigned w = 0;
     if (hipMemcpyAsync(&w, sync + 32 * groups, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
         hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
-        return a4nt_check_launch("lstm_check_timeout") == A4NT_OK ? A4NT_ERR_LAUNCH : A4NT_ERR_LAUNCH;
+        if (a4nt_check_launch("lstm_check_timeout") == A4NT_OK) a4nt_set_error("lstm_check_timeout: reading the timeout word failed");
+        return A4NT_ERR_LAUNCH;
     }
     if (w != 0) {
         a4nt_set_error("persistent LSTM sweep: inter-workgroup wait timed out (workgroups not co-resident?)");

@@ -22,6 +22,7 @@ enum {
 
 void a4nt_set_error(const char* fmt, ...);
 int a4nt_check_launch(const char* what);
+int a4nt_lstm_probe_occupancy(int device, int num_cus);     // lstm.hip, called by a4nt_init
 
 // ---------------------------------------------------------------------------------------------
 // inter-workgroup hand-off primitives (persistent LSTM kernels)

@@ -57,7 +57,8 @@ struct LstmFwdArgs {
     float* cs;              // [T][B][H] or null
     float* hN; float* cN;   // [B][H] or null
     float* hx;              // exchange [2][G][NW][MT][256]
-    unsigned* sync;         // [G] counters, 32 words apart, + timeout word at sync[32*G]
+    unsigned* sync;         // [G] counters, 32 words apart
+    unsigned* tmo;          // sticky timeout word (sync[32*G] for caller-provided sync blocks)
     int mode;               // 0: persistent sequence sweep, 1: single decode step
     int step0;              // decode: absolute step index (selects the exchange parity)
 };
@@ -86,7 +87,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bi
             wreg[jj][gt] = *reinterpret_cast<const f32x4*>(a.whh + (long long)(gt * H + u0 + fr) * H + w * (H >> 2) + 16 * jj + 4 * fq);
 
     unsigned* ctr = a.sync + 32 * g;
-    unsigned* tmo = a.sync + 32 * a.G;
+    unsigned* tmo = a.tmo;
     const unsigned blk_bytes = 256 * 4;
     const long long hx_par = (long long)a.G * a.NW * MT * 256;   // floats per parity buffer
     __amdgpu_buffer_rsrc_t rs = make_rsrc(a.hx, (unsigned)(2 * hx_par * 4));
@@ -303,6 +304,7 @@ struct LstmBwdArgs {
     float* dh0; float* dc0; // [B][H] or null
     float* gxch;            // exchange [2][G][NW consumers][NW producers][MT][256]
     unsigned* sync;
+    unsigned* tmo;
     int need_dh0;           // run the recurrent product of the last step too
 };
 
@@ -338,7 +340,7 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
                 wreg[ct][gt][i] = a.whh[(long long)(gt * H + u0 + 4 * fq + i) * H + w * (H >> 2) + 16 * ct + fr];
 
     unsigned* ctr = a.sync + 32 * g;
-    unsigned* tmo = a.sync + 32 * a.G;
+    unsigned* tmo = a.tmo;
     const unsigned blk_bytes = 256 * 4;
     const long long x_par = (long long)a.G * a.NW * a.NW * MT * 256;    // floats per parity
     __amdgpu_buffer_rsrc_t rs = make_rsrc(a.gxch, (unsigned)(2 * x_par * 4));
@@ -561,21 +563,43 @@ __global__ __launch_bounds__(256) void lstm_bwd2_kernel(LstmBwdArgs a, LstmBwdAr
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// Workgroup budget of one sweep.  256 = one workgroup per CU.  The MT = 1 kernels fit two per CU
-// (<= 224 VGPR+AGPR, 18 KB LDS), and with 512 co-resident workgroups two independent row groups
+// Workgroup budget of one sweep.  256 = one workgroup per CU.  The MT = 1 kernels up to H = 512 fit two
+// per CU (<= 224 VGPR+AGPR, 18 KB LDS), and with 512 co-resident workgroups two independent row groups
 // share every CU, so one group's hand-off latency hides behind the other's MFMA phase (B = 256,
-// H = 512: 6.7 us/step against 8.8 us/step for 256 workgroups of MT = 2).  Needs the GPU to
-// itself (all 512 resident); a4nt_lstm_set_max_workgroups(256) restores one workgroup per CU.
+// H = 512: 6.7 us/step against 8.8 us/step for 256 workgroups of MT = 2).  The H = 1024 kernels (NJ = 16)
+// hold 256 weight registers per lane: one workgroup per CU, whatever MT.  Every workgroup of a sweep
+// must be resident at once (they wait for each other), so the static caps below are cut to what
+// hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the instantiation on the initialised device
+// (a4nt_lstm_probe_occupancy, called by a4nt_init): a geometry that cannot be co-resident is an error at
+// geometry time, not a spin that runs into A4NT_SPIN_LIMIT.
+// a4nt_lstm_set_max_workgroups(256) restores one workgroup per CU for every instantiation (data
+// parallelism: leaves register space for RCCL's kernels).
 static int g_max_wgs = 512;
+#define A4NT_MAX_DEV 16
+// [device][mt index 0..2][nj index 0..4]: co-resident workgroups (CUs x occupancy, min over the forward and the
+// backward kernel); 0 = not probed (no device initialised: the static caps alone apply).  [..][1] = pair kernels.
+static int g_resident[A4NT_MAX_DEV][2][3][5];
+static int ilog2(int v) { int r = 0; while ((1 << (r + 1)) <= v) ++r; return r; }
 extern "C" int a4nt_lstm_set_max_workgroups(int n) {
     if (n != 256 && n != 512) { a4nt_set_error("a4nt_lstm_set_max_workgroups: 256 or 512"); return A4NT_ERR_ARG; }
     g_max_wgs = n;
     return A4NT_OK;
 }
+static int budget(int mt, int nj, int pair) {
+    int cap = (mt == 1 && nj < 16) ? g_max_wgs : 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < A4NT_MAX_DEV) {
+        const int res = g_resident[dev][pair][ilog2(mt)][ilog2(nj)];
+        if (res > 0 && res < cap) cap = res;
+    } else {
+        (void)hipGetLastError();      // no device (CPU-only host): static caps
+    }
+    return cap;
+}
 static int pick_mt(int B, int NW, int* G) {
     for (int mt = 1; mt <= 4; mt *= 2) {
         const int g = (B + 16 * mt - 1) / (16 * mt);
-        if ((long long)g * NW <= (mt == 1 ? g_max_wgs : 256)) { *G = g; return mt; }
+        if ((long long)g * NW <= budget(mt, NW / 4, 0)) { *G = g; return mt; }
     }
     return 0;
 }
@@ -601,11 +625,46 @@ static int pick_mt(int B, int NW, int* G) {
 
 static bool bad_h(int H) { return !(H == 64 || H == 128 || H == 256 || H == 512 || H == 1024); }
 
+// Co-residency probe (called by a4nt_init with `device` current): what the occupancy calculator says about every
+// instantiation, stored per device for budget().  Fails when some instantiation cannot hold one workgroup per CU.
+template <typename KF, typename KB> static int occ_pair(KF kf, KB kb) {
+    int nf = 0, nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, kf, 256, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kb, 256, 0) != hipSuccess) return -1;
+    return nf < nb ? nf : nb;
+}
+#define A4NT_PROBE(mt, nj)                                                                                        \
+    do {                                                                                                          \
+        const int o = occ_pair(lstm_fwd_kernel<mt, nj>, lstm_bwd_kernel<mt, nj>);                                 \
+        if (o < 1) { a4nt_set_error("a4nt_init: LSTM sweep <MT=%d,NJ=%d> cannot be resident on device %d (occupancy %d)", mt, nj, device, o); return A4NT_ERR_ARG; } \
+        g_resident[device][0][ilog2(mt)][ilog2(nj)] = o * num_cus;                                                \
+    } while (0)
+#define A4NT_PROBE2(mt, nj)                                                                                       \
+    do {                                                                                                          \
+        const int o = occ_pair(lstm_fwd2_kernel<mt, nj>, lstm_bwd2_kernel<mt, nj>);                               \
+        if (o < 1) { a4nt_set_error("a4nt_init: paired LSTM sweep <MT=%d,NJ=%d> cannot be resident on device %d (occupancy %d)", mt, nj, device, o); return A4NT_ERR_ARG; } \
+        g_resident[device][1][ilog2(mt)][ilog2(nj)] = o * num_cus;                                                \
+    } while (0)
+int a4nt_lstm_probe_occupancy(int device, int num_cus) {
+    if (device < 0 || device >= A4NT_MAX_DEV) return A4NT_OK;        // beyond the table: static caps
+    A4NT_PROBE(1, 1); A4NT_PROBE(1, 2); A4NT_PROBE(1, 4); A4NT_PROBE(1, 8); A4NT_PROBE(1, 16);
+    A4NT_PROBE(2, 1); A4NT_PROBE(2, 2); A4NT_PROBE(2, 4); A4NT_PROBE(2, 8); A4NT_PROBE(2, 16);
+    A4NT_PROBE(4, 1); A4NT_PROBE(4, 2); A4NT_PROBE(4, 4); A4NT_PROBE(4, 8); A4NT_PROBE(4, 16);
+    A4NT_PROBE2(1, 1); A4NT_PROBE2(1, 2); A4NT_PROBE2(1, 4); A4NT_PROBE2(1, 8);
+    A4NT_PROBE2(2, 1); A4NT_PROBE2(2, 2); A4NT_PROBE2(2, 4); A4NT_PROBE2(2, 8);
+    return A4NT_OK;
+}
+// co-resident workgroups the probe found for the single-sweep instantiation (0 = not probed)
+extern "C" int a4nt_lstm_resident_workgroups(int device, int mt, int H) {
+    if (device < 0 || device >= A4NT_MAX_DEV || (mt != 1 && mt != 2 && mt != 4) || bad_h(H)) return -1;
+    return g_resident[device][0][ilog2(mt)][ilog2(H / 64)];
+}
+
 extern "C" int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out) {
     if (B <= 0 || bad_h(H)) { a4nt_set_error("a4nt_lstm: H must be 64, 128, 256, 512 or 1024 (the kernels are instantiated for these), got H=%d B=%d", H, B); return A4NT_ERR_ARG; }
     int G = 0;
     const int mt = pick_mt(B, H / 16, &G);
-    if (!mt) { a4nt_set_error("a4nt_lstm: batch %d too large for one sweep at H=%d (max %d rows)", B, H, 64 * (256 / (H / 16))); return A4NT_ERR_ARG; }
+    if (!mt) { a4nt_set_error("a4nt_lstm: batch %d too large for one sweep at H=%d (%d co-resident workgroups of 64 rows x 16 units at most)", B, H, budget(4, H / 64, 0)); return A4NT_ERR_ARG; }
     *mt_out = mt; *groups_out = G;
     return A4NT_OK;
 }
@@ -625,26 +684,33 @@ extern "C" int a4nt_lstm_sync_words(int B, int H) {
 
 static bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 
+static int launch_seq_fwd(const char* what, int T, int B, int H, const float* gx, const float* gc, const float* whh,
+                          const float* h0, const float* c0, const int* lens, float* hs, float* gates, float* cs, float* hN,
+                          float* cN, float* xch, unsigned* sync, unsigned* tmo, int mt, int G, hipStream_t s) {
+    if (T <= 0 || !gx || !whh || !hs || !xch || !sync || misaligned(whh) || misaligned(xch)) {
+        a4nt_set_error("%s: bad arguments (T=%d, null or misaligned pointer)", what, T);
+        return A4NT_ERR_ARG;
+    }
+    // the counters start at zero; the timeout word is sticky (cleared by whoever reports it)
+    if (hipMemsetAsync(sync, 0, (size_t)(32 * G) * 4, s) != hipSuccess) return a4nt_check_launch(what);
+    LstmFwdArgs a;
+    a.T = T; a.B = B; a.H = H; a.G = G; a.NW = H / 16;
+    a.gx = gx; a.whh = whh; a.h0 = h0; a.c0 = c0; a.lens = lens;
+    a.cg = gc; a.ptab = nullptr; a.tok = nullptr; a.val = nullptr;
+    a.hs = hs; a.gates = gates; a.cs = cs; a.hN = hN; a.cN = cN; a.hx = xch; a.sync = sync; a.tmo = tmo; a.mode = 0; a.step0 = 0;
+    dim3 grid(G * a.NW), block(256);
+    A4NT_DISPATCH_LSTM(lstm_fwd_kernel, mt, H / 64, grid, block, s, a);
+    return a4nt_check_launch(what);
+}
+
 extern "C" int a4nt_lstm_seq_fwd(int T, int B, int H, const float* gx, const float* gc, const float* whh, const float* h0,
                                  const float* c0, const int* lens, float* hs, float* gates, float* cs, float* hN,
                                  float* cN, float* xch, unsigned* sync, void* stream) {
     int mt, G;
     int rc = a4nt_lstm_geometry(B, H, &mt, &G);
     if (rc != A4NT_OK) return rc;
-    if (T <= 0 || !gx || !whh || !hs || !xch || !sync || misaligned(whh) || misaligned(xch)) {
-        a4nt_set_error("a4nt_lstm_seq_fwd: bad arguments (T=%d, null or misaligned pointer)", T);
-        return A4NT_ERR_ARG;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(sync, 0, (size_t)(32 * G + 32) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_fwd memset");
-    LstmFwdArgs a;
-    a.T = T; a.B = B; a.H = H; a.G = G; a.NW = H / 16;
-    a.gx = gx; a.whh = whh; a.h0 = h0; a.c0 = c0; a.lens = lens;
-    a.cg = gc; a.ptab = nullptr; a.tok = nullptr; a.val = nullptr;
-    a.hs = hs; a.gates = gates; a.cs = cs; a.hN = hN; a.cN = cN; a.hx = xch; a.sync = sync; a.mode = 0; a.step0 = 0;
-    dim3 grid(G * a.NW), block(256);
-    A4NT_DISPATCH_LSTM(lstm_fwd_kernel, mt, H / 64, grid, block, s, a);
-    return a4nt_check_launch("lstm_seq_fwd");
+    return launch_seq_fwd("a4nt_lstm_seq_fwd", T, B, H, gx, gc, whh, h0, c0, lens, hs, gates, cs, hN, cN, xch, sync,
+                          sync ? sync + 32 * G : nullptr, mt, G, (hipStream_t)stream);
 }
 
 extern "C" int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const float* ptab, const long long* tok,
@@ -661,7 +727,7 @@ extern "C" int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const
     a.T = 1; a.B = B; a.H = H; a.G = G; a.NW = H / 16;
     a.gx = nullptr; a.whh = whh; a.h0 = nullptr; a.c0 = c_prev; a.lens = nullptr;
     a.cg = cg; a.ptab = ptab; a.tok = tok; a.val = val;
-    a.hs = h_out; a.gates = gates_out; a.cs = c_out; a.hN = nullptr; a.cN = nullptr; a.hx = xch; a.sync = nullptr;
+    a.hs = h_out; a.gates = gates_out; a.cs = c_out; a.hN = nullptr; a.cN = nullptr; a.hx = xch; a.sync = nullptr; a.tmo = nullptr;
     a.mode = 1; a.step0 = step;
     dim3 grid(G * a.NW), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -681,11 +747,11 @@ extern "C" int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const fl
         return A4NT_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(sync, 0, (size_t)(32 * G + 32) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_bwd memset");
+    if (hipMemsetAsync(sync, 0, (size_t)(32 * G) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_bwd memset");
     LstmBwdArgs a;
     a.T = T; a.B = B; a.H = H; a.G = G; a.NW = H / 16;
     a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens; a.dhs = dhs; a.dhN = dhN; a.dcN = dcN;
-    a.dgates = dgates; a.dh0 = dh0; a.dc0 = dc0; a.gxch = xch; a.sync = sync;
+    a.dgates = dgates; a.dh0 = dh0; a.dc0 = dc0; a.gxch = xch; a.sync = sync; a.tmo = sync + 32 * G;
     a.need_dh0 = (dh0 != nullptr) ? 1 : 0;
     dim3 grid(G * a.NW), block(256);
     A4NT_DISPATCH_LSTM(lstm_bwd_kernel, mt, H / 64, grid, block, s, a);
@@ -716,7 +782,7 @@ extern "C" int a4nt_lstm_pair_geometry(int B0, int B1, int H, int* mt_out, int* 
     const int NW = H / 16;
     for (int mt = 1; mt <= 2; mt *= 2) {
         const int g0 = (B0 + 16 * mt - 1) / (16 * mt), g1 = (B1 + 16 * mt - 1) / (16 * mt);
-        if ((long long)(g0 + g1) * NW <= (mt == 1 ? g_max_wgs : 256)) { *mt_out = mt; *g0_out = g0; *g1_out = g1; return A4NT_OK; }
+        if ((long long)(g0 + g1) * NW <= budget(mt, NW / 4, 1)) { *mt_out = mt; *g0_out = g0; *g1_out = g1; return A4NT_OK; }
     }
     return A4NT_ERR_ARG;
 }
@@ -747,13 +813,13 @@ extern "C" int a4nt_lstm_seq_fwd_pair(int H, const a4nt_lstm_fwd_problem* p0, co
             a4nt_set_error("a4nt_lstm_seq_fwd_pair: bad arguments in problem %d (T=%d, null, misaligned or shared scratch)", i, p[i]->T);
             return A4NT_ERR_ARG;
         }
-        if (hipMemsetAsync(p[i]->sync, 0, (size_t)(32 * G[i] + 32) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_fwd_pair memset");
+        if (hipMemsetAsync(p[i]->sync, 0, (size_t)(32 * G[i]) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_fwd_pair memset");
         LstmFwdArgs& q = a[i];
         q.T = p[i]->T; q.B = p[i]->B; q.H = H; q.G = G[i]; q.NW = H / 16;
         q.gx = p[i]->gx; q.whh = p[i]->whh; q.h0 = p[i]->h0; q.c0 = p[i]->c0; q.lens = p[i]->lens;
         q.cg = p[i]->gc; q.ptab = nullptr; q.tok = nullptr; q.val = nullptr;
         q.hs = p[i]->hs; q.gates = p[i]->gates; q.cs = p[i]->cs; q.hN = p[i]->hN; q.cN = p[i]->cN; q.hx = p[i]->xch;
-        q.sync = p[i]->sync; q.mode = 0; q.step0 = 0;
+        q.sync = p[i]->sync; q.tmo = p[i]->sync + 32 * G[i]; q.mode = 0; q.step0 = 0;
     }
     const int nA = G[0] * (H / 16);
     dim3 grid((G[0] + G[1]) * (H / 16)), block(256);
@@ -777,12 +843,12 @@ extern "C" int a4nt_lstm_seq_bwd_pair(int H, const a4nt_lstm_bwd_problem* p0, co
             a4nt_set_error("a4nt_lstm_seq_bwd_pair: bad arguments in problem %d (T=%d, null, misaligned or shared scratch)", i, p[i]->T);
             return A4NT_ERR_ARG;
         }
-        if (hipMemsetAsync(p[i]->sync, 0, (size_t)(32 * G[i] + 32) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_bwd_pair memset");
+        if (hipMemsetAsync(p[i]->sync, 0, (size_t)(32 * G[i]) * 4, s) != hipSuccess) return a4nt_check_launch("lstm_seq_bwd_pair memset");
         LstmBwdArgs& q = a[i];
         q.T = p[i]->T; q.B = p[i]->B; q.H = H; q.G = G[i]; q.NW = H / 16;
         q.whh = p[i]->whh; q.gates = p[i]->gates; q.cs = p[i]->cs; q.c0 = p[i]->c0; q.lens = p[i]->lens;
         q.dhs = p[i]->dhs; q.dhN = p[i]->dhN; q.dcN = p[i]->dcN;
-        q.dgates = p[i]->dgates; q.dh0 = p[i]->dh0; q.dc0 = p[i]->dc0; q.gxch = p[i]->xch; q.sync = p[i]->sync;
+        q.dgates = p[i]->dgates; q.dh0 = p[i]->dh0; q.dc0 = p[i]->dc0; q.gxch = p[i]->xch; q.sync = p[i]->sync; q.tmo = p[i]->sync + 32 * G[i];
         q.need_dh0 = (p[i]->dh0 != nullptr) ? 1 : 0;
     }
     const int nA = G[0] * (H / 16);

@@ -268,8 +268,15 @@ _ws = {}
 _sync_blocks = []
 
 
+def _ensure_init():
+    """a4nt_init on the current device before any geometry question: the budgets depend on its occupancy probe."""
+    if torch.cuda.is_available():
+        _lib.init_device(torch.cuda.current_device())
+
+
 def lstm_geometry(B, H):
     lib = _lib.load()
+    _ensure_init()
     mt, g = ctypes.c_int(0), ctypes.c_int(0)
     check(lib.a4nt_lstm_geometry(B, H, ctypes.byref(mt), ctypes.byref(g)), 'a4nt_lstm_geometry')
     return mt.value, g.value
@@ -295,6 +302,7 @@ def _lstm_ws(dev, B, H, backward):
 def lstm_rows_fit(B, H):
     """True when a batch of B rows fits one persistent sweep at hidden size H."""
     mt, g = ctypes.c_int(0), ctypes.c_int(0)
+    _ensure_init()
     return _lib.load().a4nt_lstm_geometry(int(B), int(H), ctypes.byref(mt), ctypes.byref(g)) == 0
 
 
@@ -306,7 +314,8 @@ def lstm_set_max_workgroups(n):
 
 
 def check_timeouts():
-    """Raise if any persistent sweep so far gave up on an inter-workgroup wait (host sync)."""
+    """Raise if any persistent sweep since the last call gave up on an inter-workgroup wait (host sync).  The
+    timeout word of a sync block is sticky (launches clear the counters only); it is cleared here."""
     for sync, g in _sync_blocks:
         if int(sync[32 * g].item()) != 0:
             sync[32 * g] = 0
@@ -355,6 +364,7 @@ def lstm_seq_bwd(w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0):
 def lstm_pair_geometry(B0, B1, H):
     """(mt, g0, g1) when two sweeps of B0 and B1 rows fit one launch at hidden size H, else None."""
     mt, g0, g1 = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _ensure_init()
     if _lib.load().a4nt_lstm_pair_geometry(int(B0), int(B1), int(H), ctypes.byref(mt), ctypes.byref(g0),
                                            ctypes.byref(g1)) != 0:
         return None
@@ -668,6 +678,7 @@ def paired(fn0, fn1):
         return fn0(), fn1()
     sched = _PairScheduler()
     dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    stream = torch.cuda.current_stream() if dev is not None else None     # torch's current stream is thread-local
     grad_mode = torch.is_grad_enabled()
     out = [None, None]
 
@@ -681,7 +692,11 @@ def paired(fn0, fn1):
             if dev is not None:
                 torch.cuda.set_device(dev)
             with torch.set_grad_enabled(grad_mode):
-                out[me] = fn()
+                if stream is not None:
+                    with torch.cuda.stream(stream):
+                        out[me] = fn()
+                else:
+                    out[me] = fn()
         except BaseException as e:      # re-raised in the caller's thread
             err = e
         finally:

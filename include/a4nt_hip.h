@@ -23,8 +23,11 @@ extern "C" {
 
 const char* a4nt_last_error(void);
 int a4nt_version(void);
-/* Verifies `device` is gfx950 with 256 CUs (the persistent sweeps assume 256 co-resident
- * workgroups).  Replaces nothing in the reference (it hard-codes .cuda(), char_lstm.py:98). */
+/* Verifies `device` is gfx950 with 256 CUs and asks the occupancy calculator
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor) how many workgroups of every persistent LSTM sweep
+ * instantiation can be resident at once; a4nt_lstm_geometry never hands out more than that, so a sweep
+ * whose workgroups wait for each other is refused at geometry time instead of spinning into its timeout.
+ * Replaces nothing in the reference (it hard-codes .cuda(), char_lstm.py:98). */
 int a4nt_init(int device, int* num_cus);
 
 /* C[M,N] (+)= op(A) * op(B) (+ bias[N]) on v_mfma_f32_32x32x2_f32.
@@ -65,10 +68,15 @@ int a4nt_sgemm_skinny(int transB, int M, int N, int K, const float* A, int lda, 
                       int ldc, const float* bias, int beta, int ksplit, long long slab_stride, void* stream);
 
 /* Geometry of the persistent LSTM sweeps for a batch of B rows and hidden size H
- * (H in {64, 128, 256, 512, 1024}): rows per group = 16*mt, groups*(H/16) workgroups <= 256. */
+ * (H in {64, 128, 256, 512, 1024}): rows per group = 16*mt, groups*(H/16) workgroups <= the budget of the
+ * instantiation: 512 (two workgroups per CU) for mt = 1 and H <= 512, 256 otherwise, cut to what a4nt_init
+ * found co-resident on the current device. */
 int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out);
-/* 256 (default: one workgroup per CU) or 512 (two per CU; needs the GPU to itself). */
+/* 512 (default: two workgroups per CU where the instantiation allows it; needs the GPU to itself) or
+ * 256 (one per CU for every instantiation: leaves room for other streams' kernels, e.g. RCCL). */
 int a4nt_lstm_set_max_workgroups(int n);
+/* Co-resident workgroups a4nt_init found for the <mt, H> single-sweep kernels on `device` (0: not probed). */
+int a4nt_lstm_resident_workgroups(int device, int mt, int H);
 long long a4nt_lstm_xch_floats(int B, int H, int backward);   /* exchange-buffer size (floats) */
 int a4nt_lstm_sync_words(int B, int H);                       /* sync-block size (uint32 words) */
 
@@ -124,7 +132,9 @@ long long a4nt_lstm_pair_xch_floats(int B, int H, int mt, int backward);
 int a4nt_lstm_pair_sync_words(int B, int mt);
 int a4nt_lstm_seq_fwd_pair(int H, const a4nt_lstm_fwd_problem* p0, const a4nt_lstm_fwd_problem* p1, void* stream);
 int a4nt_lstm_seq_bwd_pair(int H, const a4nt_lstm_bwd_problem* p0, const a4nt_lstm_bwd_problem* p1, void* stream);
-/* Synchronises `stream` and reports A4NT_ERR_TIMEOUT if a sweep raised its timeout word. */
+/* Synchronises `stream` and reports A4NT_ERR_TIMEOUT if a sweep raised its timeout word (the word after the
+ * `groups` counters of the sync block).  The word is sticky: launches clear the counters only, so a timeout
+ * of any earlier sweep on this sync block is still visible; the caller clears it after reporting. */
 int a4nt_lstm_check_timeout(const unsigned* sync, int groups, void* stream);
 
 /* One step of the free-running decoder (first layer): gates = cg[b] + val[b]*ptab[tok[b]] +

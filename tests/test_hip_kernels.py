@@ -186,6 +186,7 @@ def _ref_lstm(x, lens, lstm, h0, c0, up, uph, upc):
                                             (12, 128, 64, 512, False), (10, 70, 48, 256, True),
                                             (5, 300, 16, 64, True), (4, 40, 32, 1024, True),
                                             (3, 256, 16, 1024, False),
+                                            (4, 100, 16, 1024, True), (4, 128, 16, 1024, False),   # one workgroup per CU at H=1024
                                             (3, 700, 16, 512, True)])     # more rows than one sweep holds: chunked
 def test_lstm_layer_fwd_bwd(ops, T, B, I, H, ragged):
     g = torch.Generator().manual_seed(T * 1000 + B)

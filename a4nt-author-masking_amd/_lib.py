@@ -41,6 +41,7 @@ _SIGS = {
     'a4nt_lstm_xch_floats': (c_longlong, [c_int, c_int, c_int]),
     'a4nt_lstm_sync_words': (c_int, [c_int, c_int]),
     'a4nt_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'a4nt_lstm_seq_fwd_noalloc': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'a4nt_lstm_seq_bwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'a4nt_lstm_pair_geometry': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'a4nt_lstm_pair_xch_floats': (c_longlong, [c_int, c_int, c_int, c_int]),

@@ -645,8 +645,11 @@ template <typename KF, typename KB> static int occ_pair(KF kf, KB kb) {
         if (o < 1) { a4nt_set_error("a4nt_init: paired LSTM sweep <MT=%d,NJ=%d> cannot be resident on device %d (occupancy %d)", mt, nj, device, o); return A4NT_ERR_ARG; } \
         g_resident[device][1][ilog2(mt)][ilog2(nj)] = o * num_cus;                                                \
     } while (0)
+static int scratch_lookup(int device);
 int a4nt_lstm_probe_occupancy(int device, int num_cus) {
     if (device < 0 || device >= A4NT_MAX_DEV) return A4NT_OK;        // beyond the table: static caps
+    const int rcs = scratch_lookup(device);                          // a4nt_lstm_seq_fwd_noalloc's per-device buffer
+    if (rcs != A4NT_OK) return rcs;
     A4NT_PROBE(1, 1); A4NT_PROBE(1, 2); A4NT_PROBE(1, 4); A4NT_PROBE(1, 8); A4NT_PROBE(1, 16);
     A4NT_PROBE(2, 1); A4NT_PROBE(2, 2); A4NT_PROBE(2, 4); A4NT_PROBE(2, 8); A4NT_PROBE(2, 16);
     A4NT_PROBE(4, 1); A4NT_PROBE(4, 2); A4NT_PROBE(4, 4); A4NT_PROBE(4, 8); A4NT_PROBE(4, 16);
@@ -711,6 +714,66 @@ extern "C" int a4nt_lstm_seq_fwd(int T, int B, int H, const float* gx, const flo
     if (rc != A4NT_OK) return rc;
     return launch_seq_fwd("a4nt_lstm_seq_fwd", T, B, H, gx, gc, whh, h0, c0, lens, hs, gates, cs, hN, cN, xch, sync,
                           sync ? sync + 32 * G : nullptr, mt, G, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// allocation-free forward sweep (include/a4nt_hip.h: a4nt_lstm_seq_fwd_noalloc)
+// ---------------------------------------------------------------------------------------------
+// The hand-off buffer and the arrival counters of the sweep live in a file-scope device array instead of a
+// caller-provided workspace.  Any single-sweep geometry needs at most
+//   2 parities x (rows padded to 16*mt) x H floats <= 2 x (256 workgroups x 64 rows x 16 units) x 4 B = 2 MiB
+// of hand-off blocks (the 512-workgroup mode has mt = 1: half of that) and 32 x groups counter words with at most
+// 128 groups (H = 64, mt = 1), plus one timeout word.  Every GPU the library runs on holds its own copy of the
+// array until the process ends.
+#define A4NT_SCRATCH_XCH_FLOATS (2 * 256 * 64 * 16)
+#define A4NT_SCRATCH_SYNC_WORDS (32 * 128 + 32)
+#define A4NT_SCRATCH_BYTES (A4NT_SCRATCH_XCH_FLOATS * 4 + A4NT_SCRATCH_SYNC_WORDS * 4)
+static __device__ __align__(256) unsigned char scratch[A4NT_SCRATCH_BYTES];
+// device address of `scratch` per device (the name itself is a host-side stand-in, never a kernel argument)
+static void* g_scratch_ptr[A4NT_MAX_DEV];
+
+// `device` must be current.  Called by a4nt_init; the entry point repeats it for a device that was never initialised.
+static int scratch_lookup(int device) {
+    if (device < 0 || device >= A4NT_MAX_DEV) { a4nt_set_error("a4nt: device index %d beyond the %d this library tracks", device, A4NT_MAX_DEV); return A4NT_ERR_ARG; }
+    if (g_scratch_ptr[device]) return A4NT_OK;
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+        a4nt_set_error("a4nt: hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return A4NT_ERR_LAUNCH;
+    }
+    g_scratch_ptr[device] = ptr;
+    return A4NT_OK;
+}
+
+extern "C" int a4nt_lstm_seq_fwd_noalloc(int T, int B, int H, const float* gx, const float* gc, const float* whh,
+                                         const float* h0, const float* c0, const int* lens, float* hs, float* gates,
+                                         float* cs, float* hN, float* cN, unsigned* timeout_word, void* stream) {
+    int mt, G;
+    int rc = a4nt_lstm_geometry(B, H, &mt, &G);
+    if (rc != A4NT_OK) return rc;
+    const long long need = 2LL * G * (H / 16) * mt * 256;
+    if (need > A4NT_SCRATCH_XCH_FLOATS || 32 * G + 32 > A4NT_SCRATCH_SYNC_WORDS) {
+        a4nt_set_error("a4nt_lstm_seq_fwd_noalloc: B=%d, H=%d needs %lld hand-off floats and %d groups; the static scratch holds %d floats and %d groups",
+                       B, H, need, G, A4NT_SCRATCH_XCH_FLOATS, A4NT_SCRATCH_SYNC_WORDS / 32 - 1);
+        return A4NT_ERR_ARG;
+    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return a4nt_check_launch("a4nt_lstm_seq_fwd_noalloc: hipGetDevice");
+    rc = scratch_lookup(dev);
+    if (rc != A4NT_OK) return rc;
+    unsigned char* base = (unsigned char*)g_scratch_ptr[dev];      // the looked-up device address, never `scratch`
+    float* xch = (float*)base;
+    unsigned* sync = (unsigned*)(base + (size_t)A4NT_SCRATCH_XCH_FLOATS * 4);
+    unsigned* tmo = timeout_word ? timeout_word : sync + (A4NT_SCRATCH_SYNC_WORDS - 32);
+    hipStream_t s = (hipStream_t)stream;
+    // the array keeps the previous call's contents: counters are cleared by launch_seq_fwd, the hand-off blocks are
+    // all written before they are read (parity 0 by the h0 publication, parity 1 by step 0); the internal timeout
+    // word (no caller word) must start clear, or a stale 1 would end this sweep early
+    if (!timeout_word && hipMemsetAsync(tmo, 0, 4, s) != hipSuccess) return a4nt_check_launch("a4nt_lstm_seq_fwd_noalloc memset");
+    return launch_seq_fwd("a4nt_lstm_seq_fwd_noalloc", T, B, H, gx, gc, whh, h0, c0, lens, hs, gates, cs, hN, cN, xch, sync,
+                          tmo, mt, G, s);
 }
 
 extern "C" int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const float* ptab, const long long* tok,

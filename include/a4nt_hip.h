@@ -98,6 +98,21 @@ int a4nt_lstm_seq_fwd(int T, int B, int H, const float* gx, const float* gc, con
                       const int* lens, float* hs, float* gates, float* cs, float* hN, float* cN, float* xch,
                       unsigned* sync, void* stream);
 
+/* Allocation-free variant of a4nt_lstm_seq_fwd.  No counterpart in the reference and none among the workspace
+ * arguments above: it is for callers that cannot allocate device memory -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  Same arguments and results (bit for bit) as a4nt_lstm_seq_fwd
+ * without `xch` / `sync`: the hand-off buffer and the arrival counters live in a static device array inside the
+ * library (2 MiB + 16.5 KiB per GPU, held until the process ends), which covers every geometry
+ * a4nt_lstm_geometry accepts (rows padded to the group size x H <= 262144, at most 128 row groups); anything
+ * larger is refused with A4NT_ERR_ARG.  The call allocates and frees nothing.
+ *   timeout_word  device word the sweep sets to 1 when a bounded hand-off wait expired (sticky; the caller
+ *                 zeroes and reads it), or NULL: an internal word is used and nothing is reported.
+ * Every call on a GPU shares that GPU's array: calls on one stream are ordered and safe (each call clears the
+ * counters it needs); calls that overlap on one GPU (two streams, two threads) race on it. */
+int a4nt_lstm_seq_fwd_noalloc(int T, int B, int H, const float* gx, const float* gc, const float* whh, const float* h0,
+                              const float* c0, const int* lens, float* hs, float* gates, float* cs, float* hN, float* cN,
+                              unsigned* timeout_word, void* stream);
+
 /* Persistent backward sweep (BPTT) of one layer.  dgates [T][B][4H] receives the gradient w.r.t.
  * the pre-activation gates (zero where t >= lens[b]; may alias gates); weight / input gradients
  * are time-batched a4nt_sgemm calls over it.  dhs / dhN / dcN may be NULL.  dh0 NULL skips the

@@ -517,7 +517,7 @@ def fused_update(modelGen, modelEval, optimGen, optimEval, src_batch, tgt_batch,
     B = s_inps.shape[1]
     assert g_inps.shape == s_inps.shape
     from . import ops
-    if not ops.lstm_rows_fit(2 * B, modelGen.dec_hidden_size):
+    if not ops.lstm_rows_fit(2 * B, ops.padded_hidden(modelGen.dec_hidden_size)):
         # 2B rows exceed one persistent sweep at this hidden size: two passes of B rows, as the reference does
         rd = d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c, maxlen, temp, step=step,
                       reducer=reducers[1], defer=True)

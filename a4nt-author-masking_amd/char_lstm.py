@@ -71,7 +71,8 @@ class CharLstm(nn.Module):
         self.p_dec = params.get('drop_prob_decoder', 0.25)
         self.init_weights()
         self.to(params.get('device', 'cuda'))
-        ops._lib.init_device(self.decoder_W.device.index or 0)
+        if self.decoder_W.is_cuda:            # device='cpu' builds a parameter container only (init / checkpoint tools);
+            ops._lib.init_device(self.decoder_W.device.index or 0)      # every forward still needs the GPU
 
     def init_weights(self):
         a = math.sqrt(float(self.decoder_W.shape[0]))

@@ -80,7 +80,8 @@ class CharTranslator(nn.Module):
         self._noise_step = 0
         dev = params.get('device', 'cuda')
         self.to(dev)
-        ops._lib.init_device(self.char_emb.weight.device.index or 0)
+        if self.char_emb.weight.is_cuda:            # device='cpu' builds a parameter container only (init / checkpoint tools);
+            ops._lib.init_device(self.char_emb.weight.device.index or 0)      # every forward still needs the GPU
 
     def init_weights(self):
         with torch.no_grad():
@@ -282,13 +283,20 @@ class CharTranslator(nn.Module):
                 raise NotImplementedError('grad_rows needs the fused generation path')
             return self._advers_gen_generic(x, soft_in, ctxt, n_max, end_c, soft_samples, temp, n_samples, compact, dec)
         w_ih, w_hh, b_ih, b_hh = rec_layer_params(dec[0], self.en_residual, 0)
+        W_out = dec[1]
+        Hd, Hp = self.dec_hidden_size, ops.padded_hidden(self.dec_hidden_size)
+        if Hp != Hd:
+            # a hidden size between two kernel instantiations: zero-weight extra units (ops.pad_lstm_params) and
+            # zero rows of the output projection for them
+            w_ih, w_hh, b_ih, b_hh = ops.pad_lstm_params(w_ih, w_hh, b_ih, b_hh, Hd, Hp)
+            W_out = F.pad(W_out, [0, 0, 0, Hp - Hd])
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         cfg = dict(n_max=n_max, end_c=int(end_c), tau=float(temp), scale=float(self.softmax_scale),
                    hard=bool(self.gumb_type), greedy=not soft_samples, need_grad=need_grad, noise=self._noise,
                    seed=self.noise_seed, step0=self._noise_step, grad_rows=grad_rows)
         tok0 = x.tok[0] if isinstance(x, SoftSamples) else x[0].to(dev)
         samples, gen_lens, tok = gen_decode(ctxt, tok0, self.char_emb.weight, w_ih, w_hh, b_ih, b_hh,
-                                            dec[1], dec[2], cfg)
+                                            W_out, dec[2], cfg)
         self._noise_step += n_max
         char_out = list(tok.unbind(0))
         if not soft_samples:

@@ -148,6 +148,7 @@ def get_classifier(params):
 
 
 def check_hidden(h, what):
-    if h not in (64, 128, 256, 512, 1024):
-        raise ops.A4NTError('%s = %d: the gfx950 persistent LSTM kernels are instantiated for hidden sizes '
-                            '64, 128, 256, 512 and 1024' % (what, h))
+    """Any hidden size up to the largest instantiation (1024): sizes in between run zero-padded (ops.lstm_layer)."""
+    if not (1 <= int(h) <= ops.HIDDEN_SIZES[-1]):
+        raise ops.A4NTError('%s = %d: the gfx950 persistent LSTM kernels serve hidden sizes 1..%d'
+                            % (what, h, ops.HIDDEN_SIZES[-1]))

@@ -527,12 +527,61 @@ class _LstmLayer(Function):
         return dx, dw_ih, dw_hh, db, db, (dh0 if has_h0 else None), (dc0 if has_c0 else None), dgc, None
 
 
+HIDDEN_SIZES = (64, 128, 256, 512, 1024)      # instantiations of the persistent sweeps (lstm.hip)
+
+
+def padded_hidden(H):
+    """The kernel hidden size that serves a model hidden size H: the next instantiated size."""
+    for hp in HIDDEN_SIZES:
+        if H <= hp:
+            return hp
+    raise A4NTError('hidden size %d: the gfx950 persistent LSTM kernels go up to %d hidden units' % (H, HIDDEN_SIZES[-1]))
+
+
+def pad_gate_rows(t, H, Hp):
+    """[4H, ...] (gate blocks i,f,g,o of H rows) -> [4Hp, ...]: every gate block zero-padded to Hp rows."""
+    if t is None or Hp == H:
+        return t
+    tail = t.shape[1:]
+    t4 = t.reshape((4, H) + tuple(tail))
+    pad = [0, 0] * len(tail) + [0, Hp - H]
+    return torch.nn.functional.pad(t4, pad).reshape((4 * Hp,) + tuple(tail))
+
+
+def pad_gate_cols(t, H, Hp):
+    """[..., 4H] -> [..., 4Hp], same per-gate zero padding along the last dimension."""
+    if t is None or Hp == H:
+        return t
+    lead = t.shape[:-1]
+    return torch.nn.functional.pad(t.reshape(tuple(lead) + (4, H)), [0, Hp - H]).reshape(tuple(lead) + (4 * Hp,))
+
+
+def pad_last(t, H, Hp):
+    return t if (t is None or Hp == H) else torch.nn.functional.pad(t, [0, Hp - H])
+
+
+def pad_lstm_params(w_ih, w_hh, b_ih, b_hh, H, Hp):
+    """nn.LSTM parameters of hidden size H as parameters of hidden size Hp whose extra units have zero weights and
+    biases: their pre-activations are 0, so c = 0.5*c + 0.5*tanh(0) stays 0 from c0 = 0 and h = 0.5*tanh(0) = 0
+    exactly, and they feed nothing back (zero columns of W_hh).  Differentiable (padding's backward is a slice)."""
+    return (pad_gate_rows(w_ih, H, Hp), pad_gate_rows(pad_last(w_hh, H, Hp), H, Hp), pad_gate_rows(b_ih, H, Hp),
+            pad_gate_rows(b_hh, H, Hp))
+
+
 def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, lens_dev=None, h0=None, c0=None, gc=None):
     """Returns (out [T,B,H] zero-padded past each row's length, hN [B,H], cN [B,H]).
     A batch larger than one persistent sweep holds (512 rows at H = 512, 256 at H = 1024) runs as several
-    sweeps over row chunks: rows are independent."""
+    sweeps over row chunks: rows are independent.  A hidden size the kernels are not instantiated for (nn.LSTM in
+    the reference takes any, char_translator.py:78, char_lstm.py:59) runs at the next instantiated size with
+    zero-weight extra units, which stay exactly zero; the results are sliced back."""
     x = _f32(x, 'lstm input')
     B, H = x.shape[1], w_hh.shape[1]
+    Hp = padded_hidden(H)
+    if Hp != H:
+        pw = pad_lstm_params(w_ih, w_hh, b_ih, b_hh, H, Hp)
+        out, hN, cN = lstm_layer(x, pw[0], pw[1], pw[2], pw[3], lens_dev, pad_last(h0, H, Hp), pad_last(c0, H, Hp),
+                                 pad_gate_cols(gc, H, Hp))
+        return out[..., :H], hN[:, :H], cN[:, :H]
     sched = getattr(_pair_local, 'sched', None)
     if sched is not None:
         res = sched.request(_pair_local.me, (x.contiguous(), w_ih, w_hh, b_ih, b_hh, h0, c0, gc, lens_dev))

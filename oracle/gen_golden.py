@@ -329,10 +329,16 @@ def fx_translator_options(ct):
         save(name, p, **arrs)
 
 
-def fx_charlstm(cl):
+CLF_LSTM_CASES = (('clf_lstm_mp0', dict()), ('clf_lstm_mp1', dict(maxpoolrnn=1)),
+                  ('clf_lstm_mp2', dict(maxpoolrnn=2)), ('clf_lstm_res', dict(en_residual_conn=1)))
+# maxpoolrnn=3 concatenates the max over time with the last state of EVERY layer while decoder_W is sized for
+# 2H (char_lstm.py:65,309): it only type-checks with one layer
+CLF_LSTM_CASES_R2 = (('clf_lstm_mp3', dict(maxpoolrnn=3, hidden_depth=1)),)
+
+
+def fx_charlstm(cl, cases=CLF_LSTM_CASES):
     from torch.nn.utils.rnn import pack_padded_sequence as pps  # noqa: F401
-    for name, over in (('clf_lstm_mp0', dict()), ('clf_lstm_mp1', dict(maxpoolrnn=1)),
-                       ('clf_lstm_mp2', dict(maxpoolrnn=2)), ('clf_lstm_res', dict(en_residual_conn=1))):
+    for name, over in cases:
         g = torch.Generator().manual_seed(41)
         torch.manual_seed(7)
         p = eval_params(**over)
@@ -746,6 +752,57 @@ def fx_eval_translate(ct, cl):
     save('eval_translate', gp, **arrs)
 
 
+def fx_encode(ct):
+    """CharTranslator.forward_encode (char_translator.py:288-312) with and without encoder_mean_vec, hard ids and
+    soft (adv_inp) rows, gradients of a random projection of the context vector."""
+    for name, over in (('encode_meanvec', dict(encoder_mean_vec=1)), ('encode_last', dict())):
+        g = torch.Generator().manual_seed(61)
+        torch.manual_seed(19)
+        p = gen_params(**over)
+        m = ct.CharTranslator(p)
+        m.train()
+        T, B = 7, 5
+        inps, targs, lens = synth_batch(g, T, B, V0)
+        ctxt = m.forward_encode(inps, lens)
+        R = torch.randn(ctxt.shape, generator=g)
+        (ctxt * R).sum().backward()
+        arrs = dict(inps=inps, lens=np.array(lens), ctxt=ctxt, R=R)
+        arrs.update(sd_np(m, 'sd.'))
+        arrs.update(grads_np(m, 'grad.'))
+        m.zero_grad()
+        soft = torch.softmax(torch.randn(T, B, V0 + 1, generator=g) * 3, dim=-1)
+        for b, L in enumerate(lens):
+            soft[L:, b] = 0
+        soft.requires_grad_(True)
+        ctxt_s = m.forward_encode(soft, lens, adv_inp=True)
+        (ctxt_s * R).sum().backward()
+        arrs.update(dict(soft=soft.detach(), ctxt_soft=ctxt_s, dsoft=soft.grad))
+        arrs.update(grads_np(m, 'gradsoft.'))
+        save(name, p, **arrs)
+
+
+def fx_init_full(ct, cl, cc):
+    """Every initial weight of the three model classes under torch.manual_seed (a3 / a8): the product's own
+    constructors must draw the same numbers in the same order."""
+    torch.manual_seed(20)
+    gp = gen_params(enc_hidden_depth=2, dec_hidden_depth=2, learn_gumbel=True, split_generators=1)
+    ep = eval_params(decoder_mlp=20, generic_classifier=True, maxpoolrnn=1)
+    cp = dict(vocabulary_size=V0, embedding_size=E0, num_output_layers=2, decoder_cnn_nfilt=12, modeltype='cnn',
+              decoder_cnn_ks=[2, 3, 4])
+    m = ct.CharTranslator(gp)
+    e = cl.CharLstm(ep)
+    c = cc.CharCNN(cp)
+    gr = gen_params(en_residual_conn=1, enc_hidden_depth=2, dec_hidden_depth=2)
+    er = eval_params(en_residual_conn=1)
+    mr = ct.CharTranslator(gr)
+    er_m = cl.CharLstm(er)
+    arrs = dict(eval_params_json=np.array(json.dumps(ep)), cnn_params_json=np.array(json.dumps(cp)),
+                gen_res_params_json=np.array(json.dumps(gr)), eval_res_params_json=np.array(json.dumps(er)), seed=20)
+    for pre, mod in (('sdG.', m), ('sdE.', e), ('sdC.', c), ('sdGr.', mr), ('sdEr.', er_m)):
+        arrs.update(sd_np(mod, pre))
+    save('init_full', gp, **arrs)
+
+
 def fx_init(ct, cl):
     torch.manual_seed(10)
     m = ct.CharTranslator(gen_params())
@@ -776,6 +833,11 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['heads']:
         fx_charlstm_heads(cl)
         sys.exit(0)
+    if sys.argv[1:] == ['round2']:            # fixtures added in round 2
+        fx_charlstm(cl, CLF_LSTM_CASES_R2)
+        fx_encode(ct)
+        fx_init_full(ct, cl, cc)
+        sys.exit(0)
     fx_translator_options(ct)
     fx_gstep_variants(ct, cl)
     fx_loss_variants(ct, cl)
@@ -789,3 +851,6 @@ if __name__ == '__main__':
     fx_charcnn(cc)
     fx_adv_step(ct, cl, cc)
     fx_init(ct, cl)
+    fx_charlstm(cl, CLF_LSTM_CASES_R2)
+    fx_encode(ct)
+    fx_init_full(ct, cl, cc)

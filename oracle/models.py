@@ -55,11 +55,24 @@ def sample_gumbel(shape, noise, device):
     return -torch.log(-torch.log(u + eps) + eps)
 
 
+# Tests that assert exact tokens set this to a list: every arg-max decision (sampled or greedy) then appends its
+# per-row top-1 / top-2 gap, in the units the arg max is taken in, so that "exact" is claimed where the gap is far
+# above the fp32 tolerance.
+MARGIN_LOG = None
+
+
+def _log_margin(v):
+    if MARGIN_LOG is not None and v.shape[1] > 1:
+        t2 = v.detach().topk(2, dim=1).values
+        MARGIN_LOG.append(t2[:, 0] - t2[:, 1])
+
+
 def gumbel_softmax_sample(x, tau, hard, noise):
     """char_translator.py:17-28.  x: [B,V] (already multiplied by softmax_scale); tau: float, or a
     [B,1] tensor when the temperature is learnt (char_translator.py:379)."""
     g = sample_gumbel(x.shape, noise, x.device)
     y = (F.log_softmax(x, dim=1) + g) / tau
+    _log_margin(y)
     ysft = F.softmax(y, dim=1)
     if hard:
         idx = ysft.detach().argmax(dim=1, keepdim=True)
@@ -338,6 +351,7 @@ class CharTranslator(nn.Module):
                 samp_out.append(samp)
             else:
                 pred_c = dec_out.detach().argmax(dim=-1)
+                _log_margin(dec_out)
                 char_out.append(pred_c)
                 emb = self.char_emb(pred_c)
             gen_lens += (~prev_done).int()

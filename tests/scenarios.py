@@ -12,7 +12,8 @@ from golden_util import Fixture, assert_close, assert_grads_close
 MLTRAIN = ['mltrain_plain', 'mltrain_res2', 'mltrain_deep2', 'mltrain_maxpool', 'mltrain_split', 'mltrain_noenc']
 GEN_SOFT = ['gen_soft_plain', 'gen_soft_res2', 'gen_soft_split', 'gen_soft_learntau', 'gen_soft_nsamp2_st0',
             'gen_soft_advinp']
-CLF_LSTM = ['clf_lstm_mp0', 'clf_lstm_mp1', 'clf_lstm_mp2', 'clf_lstm_res']
+CLF_LSTM = ['clf_lstm_mp0', 'clf_lstm_mp1', 'clf_lstm_mp2', 'clf_lstm_res', 'clf_lstm_mp3']
+ENCODE = ['encode_meanvec', 'encode_last']
 CLF_CNN = ['clf_cnn_234', 'clf_cnn_43', 'clf_cnn_3layer_res']
 ADV_STEP = ['adv_step_lstm', 'adv_step_cnn']
 CLF_HEADS = ['clf_lstm_bidir_mp2', 'clf_lstm_mlp', 'clf_lstm_cnnhead', 'clf_lstm_generic', 'clf_lstm_compress']
@@ -96,6 +97,43 @@ def run_gen_soft(impl, device, name, tol_out, tol_grad):
     if 'dsoft' in fx:
         assert_close(x.grad, fx.t('dsoft'), tol_grad, name + ' dsoft')
     assert_grads_close(m.named_parameters(), fx.group('grad.'), tol_grad, name)
+
+
+def run_encode(impl, device, name, tol_out, tol_grad):
+    """CharTranslator.forward_encode: hard ids, then soft (adv_inp) rows on the same weights."""
+    fx = Fixture(name)
+    m = _load(impl.CharTranslator(fx.params), fx.group('sd.'), device).train()
+    lens = fx.np('lens').tolist()
+    R = fx.t('R', device)
+    ctxt = m.forward_encode(fx.t('inps'), lens)
+    (ctxt * R).sum().backward()
+    assert_close(ctxt, fx.t('ctxt'), tol_out, name + ' ctxt')
+    assert_grads_close(m.named_parameters(), fx.group('grad.'), tol_grad, name + ' hard')
+    m.zero_grad()
+    soft = fx.t('soft', device).requires_grad_(True)
+    ctxt = m.forward_encode(soft, lens, adv_inp=True)
+    (ctxt * R).sum().backward()
+    assert_close(ctxt, fx.t('ctxt_soft'), tol_out, name + ' ctxt(soft)')
+    assert_close(soft.grad, fx.t('dsoft'), tol_grad, name + ' dsoft')
+    assert_grads_close(m.named_parameters(), fx.group('gradsoft.'), tol_grad, name + ' soft')
+
+
+def run_init(impl, what='module', extra=None):
+    """Constructors under torch.manual_seed draw the reference's initial weights: same values, same RNG order
+    (models/char_translator.py:121-161, models/char_lstm.py:100-134, models/char_cnn.py:44-53)."""
+    fx = Fixture('init_full')
+    torch.manual_seed(int(fx.scalar('seed')))
+    P = lambda d: dict(d, **(extra or {}))
+    mods = [('sdG.', impl.CharTranslator(P(fx.params))), ('sdE.', impl.CharLstm(P(fx.json('eval_params_json')))),
+            ('sdC.', impl.CharCNN(P(fx.json('cnn_params_json')))),
+            ('sdGr.', impl.CharTranslator(P(fx.json('gen_res_params_json')))),
+            ('sdEr.', impl.CharLstm(P(fx.json('eval_res_params_json'))))]
+    for pre, m in mods:
+        want, got = fx.group(pre), m.state_dict()
+        assert sorted(want) == sorted(got), (pre, sorted(set(want) ^ set(got)))
+        for k, v in want.items():
+            assert got[k].shape == v.shape, (pre + k, tuple(got[k].shape), tuple(v.shape))
+            assert torch.equal(got[k].detach().cpu(), v), '%s %s%s: initial values differ from the reference under the same seed' % (what, pre, k)
 
 
 def run_gen_greedy(impl, device):

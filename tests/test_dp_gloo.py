@@ -49,7 +49,8 @@ def _worker(rank, world, port, out_q, overlap):
     cnt = red.all_reduce_scalars(torch.tensor([1.0 + rank, 10.0]))
     w_tok = float(red.token_weight(10 if rank == 0 else 30))
     if rank == 0:
-        out_q.put(({n: p.grad.clone() for n, p in m.named_parameters()}, cnt, issued_early, w_tok))
+        # by value (numpy): tensors travel as shared-memory handles that die with this process
+        out_q.put(({n: p.grad.numpy().copy() for n, p in m.named_parameters()}, cnt.tolist(), issued_early, w_tok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,7 +75,7 @@ def test_two_ranks_equal_one_big_batch(overlap):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert torch.allclose(cnt, torch.tensor([3.0, 20.0]))
+    assert torch.allclose(torch.tensor(cnt), torch.tensor([3.0, 20.0]))
     assert abs(w_tok - 10 * 2 / 40.0) < 1e-6          # rank 0 holds 10 of the 40 valid tokens
     if overlap:
         # nothing can be issued while the order is being learnt; afterwards most buckets go out inside backward()
@@ -82,7 +83,7 @@ def test_two_ranks_equal_one_big_batch(overlap):
     else:
         assert issued_early == [0, 0, 0]
     for n, p in ref.named_parameters():
-        assert torch.allclose(grads[n], p.grad, rtol=1e-5, atol=1e-7), n
+        assert torch.allclose(torch.from_numpy(grads[n]), p.grad, rtol=1e-5, atol=1e-7), n
 
 
 def test_single_process_is_noop():

@@ -137,3 +137,64 @@ def test_generation_ends_long_before_n_max():
     assert torch.equal(out['hip'][1], out['ref'][1]) and torch.equal(out['hip'][2], out['ref'][2])
     assert_close(out['hip'][0], out['ref'][0], TOL_OUT, 'samples')
     assert_grads_close(hip.named_parameters(), _grads(ref), TOL_GRAD, 'early end')
+
+
+# ------------------------------------------------------------------------------------------
+# hidden sizes the kernels are not instantiated for (nn.LSTM in the reference takes any:
+# models/char_translator.py:74-90, models/char_lstm.py:55-59): run zero-padded at the next instantiated size
+@pytest.mark.parametrize('Hx', [96, 300, 20])
+def test_any_hidden_size(Hx):
+    gp = dict(GP, enc_hidden_size=Hx, dec_hidden_size=Hx)
+    ep = dict(EP, hidden_size=Hx)
+    B, lens = 6, [7, 7, 5, 4, 2, 1]
+    # classifier, two stacked layers
+    ref, hip, impl = _pair('CharLstm', ep)
+    assert hip.state_dict()['rec_layers.weight_hh_l1'].shape == (4 * Hx, Hx)         # state_dict keeps the real size
+    x = _ids(B, lens, 13)
+    labels = torch.arange(B) % 2
+    out = {}
+    for tag, m in (('ref', ref), ('hip', hip)):
+        logits, feat = m.forward_classify(x, lens=lens)
+        F.cross_entropy(logits, labels.to(logits.device)).backward()
+        out[tag] = (logits.detach().cpu(), feat.detach().cpu())
+    impl.check_timeouts()
+    assert out['hip'][1].shape == (B, Hx)
+    assert_close(out['hip'][0], out['ref'][0], TOL_OUT, 'H=%d logits' % Hx)
+    assert_close(out['hip'][1], out['ref'][1], TOL_OUT, 'H=%d features' % Hx)
+    assert_grads_close(hip.named_parameters(), _grads(ref), TOL_GRAD, 'H=%d classifier' % Hx)
+    # translator: teacher forced, then free-running generation with pinned noise (fused decode loop)
+    ref, hip, impl = _pair('CharTranslator', gp)
+    inps, targs = _ids(B, lens, 14), _ids(B, lens, 15)
+    auths = torch.arange(B) % 2
+    for tag, m in (('ref', ref), ('hip', hip)):
+        scores, _ = m.forward_mltrain(inps, lens, inps, lens, auths=auths)
+        F.cross_entropy(pps(scores, lens)[0], pps(targs.to(scores.device), lens)[0]).backward()
+        out[tag] = scores.detach().cpu()
+    impl.check_timeouts()
+    assert_close(out['hip'], out['ref'], TOL_OUT, 'H=%d scores' % Hx)
+    assert_grads_close(hip.named_parameters(), _grads(ref), TOL_GRAD, 'H=%d mltrain' % Hx)
+    with torch.no_grad():
+        ref.decoder_W.mul_(30.0)
+        hip.decoder_W.mul_(30.0)
+    ref.zero_grad(); hip.zero_grad()
+    g = torch.Generator().manual_seed(19)
+    n_max, Vp = 6, ref.decoder_W.shape[1]
+    noise = [torch.rand(B, Vp, generator=g) for _ in range(n_max)]
+    R = torch.randn(n_max, B, Vp, generator=g)
+    for tag, m, dev in (('ref', ref, 'cpu'), ('hip', hip, 'cuda')):
+        m.set_noise([u.clone().to(dev) for u in noise])
+        s, gl, co = m.forward_advers_gen(inps, lens, soft_samples=True, temp=0.5, n_max=n_max, end_c=7, auths=auths)
+        samp = torch.stack(list(s), 0)
+        (samp * R[:samp.shape[0]].to(dev)).sum().backward()
+        out[tag] = (samp.detach().cpu(), torch.stack(list(co), 0).cpu().long(), gl.cpu().long())
+    impl.check_timeouts()
+    assert torch.equal(out['hip'][1], out['ref'][1]) and torch.equal(out['hip'][2], out['ref'][2])
+    assert_close(out['hip'][0], out['ref'][0], TOL_OUT, 'H=%d samples' % Hx)
+    assert_grads_close(hip.named_parameters(), _grads(ref), TOL_GRAD, 'H=%d generation' % Hx)
+    with torch.no_grad():
+        toks = []
+        for m in (ref, hip):
+            m.eval()
+            _, gl, co = m.forward_advers_gen(inps, lens, soft_samples=False, n_max=n_max, end_c=-1, auths=auths)
+            toks.append(torch.stack(list(co), 0).cpu().long())
+    assert torch.equal(toks[0], toks[1]), 'H=%d greedy tokens' % Hx

@@ -35,6 +35,12 @@ def test_gen_soft(impl, name):
     impl.check_timeouts()
 
 
+@pytest.mark.parametrize('name', sc.ENCODE)
+def test_encode(impl, name):
+    sc.run_encode(impl, 'cuda', name, TOL_OUT, TOL_GRAD)
+    impl.check_timeouts()
+
+
 def test_gen_greedy(impl):
     sc.run_gen_greedy(impl, 'cuda')
 

@@ -76,6 +76,15 @@ def test_eval_translate():
     sc.run_eval_translate(oracle, 'cpu', oracle.eval_forward_pass, TOL_OUT)
 
 
+@pytest.mark.parametrize('name', sc.ENCODE)
+def test_encode(name):
+    sc.run_encode(oracle, 'cpu', name, TOL_OUT, TOL_GRAD)
+
+
+def test_init_full():
+    sc.run_init(oracle, 'oracle')
+
+
 def test_init_quirks():
     """Forget-gate bias fill covers indices H+1..2H-1 only (index H untouched), value 1.0 for the
     translator and 2.0 for the classifier; decoder_W ranges (char_translator.py:121-161,

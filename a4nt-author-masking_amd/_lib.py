@@ -64,6 +64,11 @@ _SIGS = {
     'a4nt_embed_bwd': (c_int, [c_longlong, c_int, c_int, P, P, P, c_int, P, c_longlong, P]),
     'a4nt_colsum': (c_int, [c_int, c_int, P, c_int, P, c_int, P]),
     'a4nt_slab_reduce': (c_int, [c_int, c_longlong, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, P]),
+    'a4nt_conv1d_tm': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_float, P, c_int, c_int,
+                               c_int, c_int, c_int, P, P]),
+    'a4nt_maxkey_init': (c_int, [c_int, c_int, P, c_int, P]),
+    'a4nt_maxkey_decode': (c_int, [c_int, c_int, P, P, c_int, P, P]),
+    'a4nt_maxtime_scatter_bwd': (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_float, P, c_int, P]),
     'a4nt_lrelu_maxtime': (c_int, [c_int, c_int, c_int, P, c_int, c_float, c_int, P, c_int, P, P]),
     'a4nt_lrelu_maxtime_bwd': (c_int, [c_int, c_int, c_int, P, c_int, c_float, P, c_int, P, P]),
 }

@@ -2,10 +2,11 @@
 n_layers x {parallel Conv1d(K, padding=K//2) -> leaky_relu -> pad to the last branch's length ->
 concat -> dropout [-> residual every 2nd layer]} -> max over time -> linear.
 
-Each Conv1d runs as K shifted MFMA GEMMs over the time-major [T,B,C] activations (a4nt_sgemm with
-accumulate); when the last layer feeds the global max-pool directly (no active dropout, no
-residual on that layer) leaky_relu + zero-pad + max-over-time are one fused kernel
-(a4nt_lrelu_maxtime).  Padding positions are not masked (`lens` unused), as in the reference.
+Each Conv1d branch is ONE launch of a4nt_conv1d_tm: the K taps are shifted views of the time-major [T*B, C]
+activations and accumulate in the MFMA accumulators; bias, leaky_relu and the placement into the zero-padded,
+concatenated layer output happen in its epilogue, and when the last layer feeds the global max-pool directly
+(no active dropout, no residual on that layer) so does the max over time -- the pre-activations are never
+written.  Padding positions are not masked (`lens` unused), as in the reference.
 """
 import math
 
@@ -18,52 +19,176 @@ from . import ops
 from .gen_decode import SoftSamples, sample_embed
 
 
+def _conv_launch(x2, T, B, wt, bias, pad, act, slope, out=None, ldo=0, t_lo=0, t_hi=None, t_off=0, beta=0, keys=None):
+    """One a4nt_conv1d_tm launch.  x2 [T*B, C] time major; wt [K][C][F] taps; the K taps accumulate in the MFMA
+    accumulators of one kernel (no per-tap read-modify-write of the output)."""
+    lib = ops._lib.load()
+    K, C, Fo = wt.shape
+    Tout = T + 2 * pad - K + 1
+    t_hi = Tout if t_hi is None else t_hi
+    ops.check(lib.a4nt_conv1d_tm(T, B, C, Fo, K, pad, ops._p(x2), x2.stride(0), ops._p(wt), ops._p(bias), int(act),
+                                 float(slope), ops._p(out), int(ldo), int(t_lo), int(t_hi), int(t_off), int(beta),
+                                 ops._p(keys), ops._s()), 'a4nt_conv1d_tm')
+    return Tout
+
+
+def _conv_grads(x2, T, B, weight, pad, dpre2, Tout, need_dx, need_dw, need_db, dx_acc=None):
+    """Gradients of one Conv1d given d(pre) [Tout*B, F]: dx through the same kernel with the flipped, transposed
+    taps (added into dx_acc when given), dW as one time-batched TN product per tap over shifted views, db."""
+    Fo, C, K = weight.shape
+    dx = dx_acc
+    if need_dx:
+        wflip = weight.permute(2, 0, 1).flip(0).contiguous()                      # [K][F][C]
+        if dx is None:
+            dx = torch.empty((T * B, C), device=x2.device)
+            beta = 0
+        else:
+            beta = 1
+        _conv_launch(dpre2, Tout, B, wflip, None, K - 1 - pad, 0, 0.0, out=dx, ldo=C, beta=beta)
+    dw = None
+    if need_dw:
+        dwk = torch.zeros((K, Fo, C), device=x2.device)
+        for k in range(K):
+            t0, t1 = max(0, pad - k), min(Tout, T + pad - k)            # output steps whose tap k is inside the input
+            if t1 > t0:
+                s0 = t0 + k - pad
+                dwk[k].copy_(ops.gemm_auto(dpre2[t0 * B:t1 * B], x2[s0 * B:(s0 + t1 - t0) * B], transA=True))
+        dw = dwk.permute(1, 2, 0).contiguous()
+    db = ops.colsum(dpre2) if need_db else None
+    return dx, dw, db
+
+
 class _Conv1dTM(Function):
     """x [T,B,C] (time major), weight [F,C,K], bias [F], zero padding `pad` (default K//2) on both sides
-    -> pre-activations [Tout,B,F]."""
+    -> pre-activations [Tout,B,F] (nn.Conv1d, char_cnn.py:84; char_lstm.py:75,324)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, pad=None):
         T, B, C = x.shape
         Fo, _, K = weight.shape
         pad = K // 2 if pad is None else int(pad)
-        Tout = T + 2 * pad - K + 1
         x2 = x.contiguous().view(T * B, C)
-        wk = weight.permute(2, 0, 1).contiguous()              # [K][F][C]
-        out = bias.view(1, Fo).expand(Tout * B, Fo).contiguous()
-        for k in range(K):
-            t0, t1 = max(0, pad - k), min(Tout, T + pad - k)    # output steps whose tap k is inside the input
-            if t1 > t0:
-                s0 = t0 + k - pad
-                ops.gemm(x2[s0 * B:(s0 + t1 - t0) * B], wk[k], transB=True, out=out[t0 * B:t1 * B], beta=1)
-        ctx.save_for_backward(x2, wk)
+        wt = weight.permute(2, 1, 0).contiguous()              # [K][C][F]
+        Tout = T + 2 * pad - K + 1
+        out = torch.empty((Tout * B, Fo), device=x.device)
+        _conv_launch(x2, T, B, wt, bias, pad, 0, 0.0, out=out, ldo=Fo)
+        ctx.save_for_backward(x2, weight)
         ctx.dims = (T, B, C, Fo, K, pad, Tout)
         return out.view(Tout, B, Fo)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, wk = ctx.saved_tensors
+        x2, weight = ctx.saved_tensors
         T, B, C, Fo, K, pad, Tout = ctx.dims
         d2 = dout.contiguous().view(Tout * B, Fo)
-        dx = torch.zeros((T * B, C), device=d2.device) if ctx.needs_input_grad[0] else None
-        dwk = torch.zeros((K, Fo, C), device=d2.device) if ctx.needs_input_grad[1] else None
-        for k in range(K):
-            t0, t1 = max(0, pad - k), min(Tout, T + pad - k)
-            if t1 <= t0:
-                continue
-            s0 = t0 + k - pad
-            xs, ds = x2[s0 * B:(s0 + t1 - t0) * B], d2[t0 * B:t1 * B]
-            if dx is not None:
-                ops.gemm(ds, wk[k], out=dx[s0 * B:(s0 + t1 - t0) * B], beta=1)
-            if dwk is not None:
-                dwk[k].copy_(ops.gemm_auto(ds, xs, transA=True))
-        dw = dwk.permute(1, 2, 0).contiguous() if dwk is not None else None
-        db = ops.colsum(d2) if ctx.needs_input_grad[2] else None
+        dx, dw, db = _conv_grads(x2, T, B, weight, pad, d2, Tout, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                 ctx.needs_input_grad[2])
         return (dx.view(T, B, C) if dx is not None else None), dw, db, None
 
 
+def _branch_geometry(T, ks):
+    """Per branch (K, pad, Tout, t_lo, t_hi, t_off, n_pad) and the common length: every branch is padded with zeros
+    (or cropped, when it is longer) to the LAST kernel size's output length, left d//2, right int(d/2 + 0.5)
+    (char_cnn.py:85-86)."""
+    touts = [T + 2 * (K // 2) - K + 1 for K in ks]
+    max_sz = touts[-1]
+    geo = []
+    for K, Tout in zip(ks, touts):
+        d = max_sz - Tout
+        left, right = d // 2, int((d / 2. + 0.5) // 1)
+        geo.append((K, K // 2, Tout, max(0, -left), Tout - max(0, -right), max(0, left), max(0, left) + max(0, right)))
+    return geo, max_sz
+
+
+class _ConvLayer(Function):
+    """One CharCNN layer (char_cnn.py:83-87): for every kernel size a Conv1d + leaky_relu whose output lands,
+    zero-padded / cropped to the common length, in its column slice of the concatenated activations -- one
+    launch per branch, nothing else.  apply(x, ks, slope, w_0, b_0, w_1, b_1, ...) -> [Tcommon, B, nb*F]."""
+
+    @staticmethod
+    def forward(ctx, x, ks, slope, *wb):
+        T, B, C = x.shape
+        x2 = x.contiguous().view(T * B, C)
+        geo, max_sz = _branch_geometry(T, ks)
+        Fo = wb[0].shape[0]
+        nb = len(ks)
+        out = torch.zeros((max_sz, B, nb * Fo), device=x.device)         # zero: the pad positions
+        for i, (K, pad, Tout, t_lo, t_hi, t_off, _) in enumerate(geo):
+            wt = wb[2 * i].permute(2, 1, 0).contiguous()
+            _conv_launch(x2, T, B, wt, wb[2 * i + 1], pad, 1, slope, out=out.view(max_sz * B, nb * Fo)[:, i * Fo:],
+                         ldo=nb * Fo, t_lo=t_lo, t_hi=t_hi, t_off=t_off)
+        ctx.save_for_backward(x2, out, *wb[0::2])
+        ctx.meta = (T, B, C, Fo, geo, max_sz, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, out = ctx.saved_tensors[:2]
+        weights = ctx.saved_tensors[2:]
+        T, B, C, Fo, geo, max_sz, slope = ctx.meta
+        nb = len(geo)
+        # leaky_relu keeps the sign: its derivative is read off the saved output
+        dact = torch.where(out > 0, dout, dout * slope)
+        dx, grads = None, []
+        for i, (K, pad, Tout, t_lo, t_hi, t_off, _) in enumerate(geo):
+            dpre = torch.zeros((Tout, B, Fo), device=dout.device)
+            dpre[t_lo:t_hi] = dact[t_off:t_off + (t_hi - t_lo), :, i * Fo:(i + 1) * Fo]
+            dx, dw, db = _conv_grads(x2, T, B, weights[i], pad, dpre.view(Tout * B, Fo), Tout, ctx.needs_input_grad[0],
+                                     ctx.needs_input_grad[3 + 2 * i], ctx.needs_input_grad[4 + 2 * i], dx_acc=dx)
+            grads += [dw, db]
+        return (dx.view(T, B, C) if dx is not None else None, None, None) + tuple(grads)
+
+
+class _ConvLayerMax(Function):
+    """The last CharCNN layer when it feeds the global max-pool directly (char_cnn.py:83-92): Conv1d + leaky_relu +
+    zero-pad + max over time in the conv kernel's epilogue, one launch per branch; the pre-activations are never
+    written.  apply(x, ks, slope, w_0, b_0, ...) -> feat [B, nb*F]."""
+
+    @staticmethod
+    def forward(ctx, x, ks, slope, *wb):
+        lib = ops._lib.load()
+        T, B, C = x.shape
+        x2 = x.contiguous().view(T * B, C)
+        geo, max_sz = _branch_geometry(T, ks)
+        Fo = wb[0].shape[0]
+        nb = len(ks)
+        feat = torch.empty((B, nb * Fo), device=x.device)
+        arg = torch.empty((nb, B, Fo), device=x.device, dtype=torch.int32)
+        keys = torch.empty((nb, B, Fo), device=x.device, dtype=torch.int64)
+        s = ops._s()
+        for i, (K, pad, Tout, t_lo, t_hi, t_off, n_pad) in enumerate(geo):
+            wt = wb[2 * i].permute(2, 1, 0).contiguous()
+            ops.check(lib.a4nt_maxkey_init(B, Fo, ops._p(keys[i]), int(n_pad > 0), s), 'a4nt_maxkey_init')
+            _conv_launch(x2, T, B, wt, wb[2 * i + 1], pad, 1, slope, t_lo=t_lo, t_hi=t_hi, keys=keys[i])
+            ops.check(lib.a4nt_maxkey_decode(B, Fo, ops._p(keys[i]), ops._p(feat[:, i * Fo:]), nb * Fo, ops._p(arg[i]), s),
+                      'a4nt_maxkey_decode')
+        ctx.save_for_backward(x2, feat, arg, *wb[0::2])
+        ctx.meta = (T, B, C, Fo, geo, slope)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        lib = ops._lib.load()
+        x2, feat, arg = ctx.saved_tensors[:3]
+        weights = ctx.saved_tensors[3:]
+        T, B, C, Fo, geo, slope = ctx.meta
+        nb = len(geo)
+        dfeat = dfeat.contiguous()
+        dx, grads = None, []
+        for i, (K, pad, Tout, t_lo, t_hi, t_off, _) in enumerate(geo):
+            dpre = torch.empty((Tout * B, Fo), device=dfeat.device)
+            ops.check(lib.a4nt_maxtime_scatter_bwd(Tout, B, Fo, ops._p(dfeat[:, i * Fo:]), nb * Fo, ops._p(feat[:, i * Fo:]),
+                                                   nb * Fo, ops._p(arg[i]), float(slope), ops._p(dpre), Fo, ops._s()),
+                      'a4nt_maxtime_scatter_bwd')
+            dx, dw, db = _conv_grads(x2, T, B, weights[i], pad, dpre, Tout, ctx.needs_input_grad[0],
+                                     ctx.needs_input_grad[3 + 2 * i], ctx.needs_input_grad[4 + 2 * i], dx_acc=dx)
+            grads += [dw, db]
+        return (dx.view(T, B, C) if dx is not None else None, None, None) + tuple(grads)
+
+
 class _LreluMaxTime(Function):
-    """feat[b,f] = max over time of leaky_relu(pre[t,b,f]) with `pad` zero positions joining the max."""
+    """feat[b,f] = max over time of leaky_relu(pre[t,b,f]) with `pad` zero positions joining the max (the
+    CNN-over-hidden-states head of CharLstm, char_lstm.py:324-325)."""
 
     @staticmethod
     def forward(ctx, pre, pad, slope):
@@ -162,25 +287,15 @@ class CharCNN(nn.Module):
             drop_active = self.training and self.p_dec > 0.0
             feat = None
             for i in range(self.n_layers):
-                pres = [_Conv1dTM.apply(inputs[-1], conv.weight, conv.bias) for conv in self.decoder_cnn[i]]
-                max_sz = pres[-1].shape[0]
+                wb = [t for conv in self.decoder_cnn[i] for t in (conv.weight, conv.bias)]
                 res_here = self.decoder_cnn_residual and i > 0 and (i % 2) == 0
                 if i == self.n_layers - 1 and not drop_active and not res_here:
-                    feats = []
-                    for p in pres:
-                        d = max_sz - p.shape[0]
-                        left, right = d // 2, int((d / 2. + 0.5) // 1)
-                        # a negative pad crops (FN.pad semantics, char_cnn.py:86: branch longer than the last one)
-                        p = p[max(0, -left):p.shape[0] - max(0, -right)]
-                        feats.append(_LreluMaxTime.apply(p, max(0, left) + max(0, right), 0.01))
-                    feat = torch.cat(feats, dim=1)
+                    # conv + leaky_relu + zero-pad + max over time: one launch per kernel size
+                    feat = _ConvLayerMax.apply(inputs[-1], tuple(self.cnn_ks), 0.01, *wb)
                     break
-                padded = []
-                for p in pres:
-                    d = max_sz - p.shape[0]
-                    left, right = d // 2, int((d / 2. + 0.5) // 1)
-                    padded.append(F.pad(F.leaky_relu(p), (0, 0, 0, 0, left, right)))
-                nxt = self._drop(torch.cat(padded, dim=2), self.p_dec)
+                act = _ConvLayer.apply(inputs[-1], tuple(self.cnn_ks), 0.01, *wb)
+                max_sz = act.shape[0]
+                nxt = self._drop(act, self.p_dec)
                 if res_here:
                     prev = inputs[-2]
                     nxt = nxt + F.pad(prev, (0, 0, 0, 0, max_sz - prev.shape[0], 0))

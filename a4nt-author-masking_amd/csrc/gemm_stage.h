@@ -120,3 +120,24 @@ struct StageMC {
     }
 };
 
+
+// One BKT-deep step of a (64*WM) x (64*WN) workgroup tile from k-major LDS tiles ([BKT][rows + LPAD]): wave (wm, wn)
+// owns WM x WN tiles of 32x32 (v_mfma_f32_32x32x2_f32, 16 accumulator registers each).
+template <int WM, int WN, int BKT>
+__device__ __forceinline__ void mma_tile_k(const float* as, const float* bs, int lane, int wm, int wn, f32x16 (&acc)[WM][WN]) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+#pragma unroll
+    for (int kk = 0; kk < BKT; kk += 2) {
+        const int kr = kk + (lane >> 5);
+        float a[WM], b[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = as[kr * (BM + LPAD) + wm + 32 * i + (lane & 31)];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[j] = bs[kr * (BN + LPAD) + wn + 32 * j + (lane & 31)];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}

@@ -43,21 +43,7 @@ template <int R> struct StageSel<true, R> { typedef StageMC<R, BK> type; };
 
 template <int WM, int WN>
 __device__ __forceinline__ void mma_tile(const float* as, const float* bs, int lane, int wm, int wn, f32x16 (&acc)[WM][WN]) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-        const int kr = kk + (lane >> 5);
-        float a[WM], b[WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) a[i] = as[kr * (BM + LPAD) + wm + 32 * i + (lane & 31)];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) b[j] = bs[kr * (BN + LPAD) + wn + 32 * j + (lane & 31)];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+    mma_tile_k<WM, WN, BK>(as, bs, lane, wm, wn, acc);
 }
 
 // K loop.  EA / EB: the "mn contiguous" operand of this workgroup is an edge tile (dword loads).

@@ -36,7 +36,7 @@ int a4nt_init(int device, int* num_cus);
  * Replaces: x.mm(W) of the vocab projection (char_translator.py:279,377), the soft-embedding
  * contractions (char_translator.py:214,299,329,381; char_lstm.py:289; char_cnn.py:73), the
  * x*W_ih^T half of nn.LSTM (char_translator.py:182-197; char_lstm.py:148-163), nn.Conv1d as
- * shifted GEMMs (char_cnn.py:84), the classifier heads (char_lstm.py:329; char_cnn.py:96) and
+ * shifted GEMMs' weight gradients (char_cnn.py:84), the classifier heads (char_lstm.py:329; char_cnn.py:96) and
  * every autograd backward of those. */
 int a4nt_sgemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                float* C, int ldc, const float* bias, int beta, int ksplit, long long slab_stride, void* stream);
@@ -226,6 +226,31 @@ int a4nt_colsum(int M, int N, const float* A, int lda, float* out, int accumulat
 /* out[r][c] = sum_s slabs[s*stride + r*lds + c0 + c] (+ add[r][c])  (split-K reduction). */
 int a4nt_slab_reduce(int S, long long stride, int R, int C, const float* slabs, int lds, int c0, const float* add,
                      int lda, float* out, int ldo, void* stream);
+
+/* Conv1d over time-major activations, all K taps accumulated in the MFMA accumulators of one launch, with bias,
+ * leaky_relu, placement into a (zero-padded / cropped, concatenated) output and the max over time in the epilogue.
+ *   x [T*B][ldx] (row t*B + b, C channels)      w [K][C][F] taps (nn.Conv1d weight [F][C][K] re-laid)
+ *   y[t][b][f] = bias[f] + sum_k sum_c x[t + k - pad][b][c] * w[k][c][f],  t in [0, Tout = T + 2*pad - K + 1)
+ *   (pad < 0 crops: rows outside [0, T) simply read as zero)      act = 1: y = leaky_relu(y, slope)
+ *   out (may be NULL): steps [t_lo, t_hi) are written at row ((t - t_lo + t_off)*B + b), columns [0, F), leading
+ *       dimension ldo (point it at a column slice of the concatenated layer output); beta = 1 accumulates
+ *   maxkey (may be NULL): [B][F] 64-bit keys (a4nt_maxkey_init before, a4nt_maxkey_decode after): running max over
+ *       steps [t_lo, t_hi) of y as (ordered value bits, step) -- order independent, hence deterministic.
+ * With the taps flipped and transposed (w'[k][f][c] = W[f][c][K-1-k], pad' = K-1-pad, x = d(pre)) the same call
+ * computes the data gradient.  Replaces: nn.Conv1d + FN.leaky_relu + FN.pad + torch.cat + FN.max_pool1d
+ * (char_cnn.py:83-92) and the conv-over-hidden-states head (char_lstm.py:75,324), and their autograd backward. */
+int a4nt_conv1d_tm(int T, int B, int C, int F, int K, int pad, const float* x, int ldx, const float* w,
+                   const float* bias, int act, float slope, float* out, int ldo, int t_lo, int t_hi, int t_off,
+                   int beta, unsigned long long* maxkey, void* stream);
+/* keys = "nothing yet" (with_pad = 0) or "a zero-pad position" (value 0, wins ties; with_pad = 1). */
+int a4nt_maxkey_init(int B, int F, unsigned long long* keys, int with_pad, void* stream);
+/* feat[b][f] = winning value, argmax[b][f] = winning step or -1 when a zero-pad position won. */
+int a4nt_maxkey_decode(int B, int F, const unsigned long long* keys, float* feat, int ldf, int* argmax, void* stream);
+/* dpre [Tout][B][ldp] = 0 except dpre[argmax[b][f]][b][f] = dfeat[b][f] * (feat[b][f] > 0 ? 1 : slope):
+ * backward of leaky_relu + max over time from the decoded keys (leaky_relu keeps the sign).
+ * Replaces: autograd backward of FN.max_pool1d(FN.leaky_relu(.)) (char_cnn.py:84-92). */
+int a4nt_maxtime_scatter_bwd(int Tout, int B, int F, const float* dfeat, int ldd, const float* feat, int ldf,
+                             const int* argmax, float slope, float* dpre, int ldp, void* stream);
 
 /* CharCNN epilogue: leaky_relu + (zero-padded) max over time of [Tout][B][F] conv pre-activations,
  * and its backward (in place over pre).  Replaces: FN.leaky_relu + FN.pad + FN.max_pool1d

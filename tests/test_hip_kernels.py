@@ -388,6 +388,46 @@ def test_conv1d_time_major(ops, K):
     assert_close(bg.grad, conv.bias.grad, TOLG, 'conv db')
 
 
+@pytest.mark.parametrize('ks', [[2, 3, 4], [4, 3], [3, 5], [5, 2], [1]])
+@pytest.mark.parametrize('T,B,C,Fo', [(9, 5, 24, 12), (70, 37, 40, 100), (33, 4, 16, 130)])
+def test_conv_layer_fused(ops, ks, T, B, C, Fo):
+    """One launch per branch: conv (taps accumulated in the MFMA accumulators) + bias + leaky_relu + zero-pad /
+    crop to the last branch's length, written into the concatenated output (_ConvLayer) or max-pooled over time
+    in the epilogue (_ConvLayerMax), against nn.Conv1d + leaky_relu + F.pad + cat + max (char_cnn.py:83-92)."""
+    from a4nt_amd.char_cnn import _ConvLayer, _ConvLayerMax
+    torch.manual_seed(7)
+    convs = [nn.Conv1d(C, Fo, K, padding=K // 2) for K in ks]
+    x = _rand(T, B, C, seed=55)
+
+    def ref(xc):
+        outs = [F.leaky_relu(cv(xc.permute(1, 2, 0))) for cv in convs]          # [B,F,Tout]
+        max_sz = outs[-1].shape[2]
+        outs = [F.pad(o, ((max_sz - o.shape[2]) // 2, int((max_sz - o.shape[2]) / 2. + 0.5))) for o in outs]
+        return torch.cat(outs, dim=1)                                            # [B, nb*F, Tcommon]
+
+    for mode in ('cat', 'max'):
+        for cv in convs:
+            cv.zero_grad()
+        xc = x.clone().requires_grad_(True)
+        r = ref(xc)
+        r = r.permute(2, 0, 1) if mode == 'cat' else r.max(dim=2)[0]
+        up = _rand(*r.shape, seed=56)
+        (r * up).sum().backward()
+        xg = x.cuda().requires_grad_(True)
+        wb = [t.detach().clone().cuda().requires_grad_(True) for cv in convs for t in (cv.weight, cv.bias)]
+        fn = _ConvLayer if mode == 'cat' else _ConvLayerMax
+        out = fn.apply(xg, tuple(ks), 0.01, *wb)
+        (out * up.cuda()).sum().backward()
+        assert_close(out, r.detach(), TOL, 'conv layer %s' % mode)
+        assert_close(xg.grad, xc.grad, TOLG, 'conv layer %s dx' % mode)
+        for i, cv in enumerate(convs):
+            assert_close(wb[2 * i].grad, cv.weight.grad, TOLG, 'conv layer %s dW%d' % (mode, i))
+            assert_close(wb[2 * i + 1].grad, cv.bias.grad, TOLG, 'conv layer %s db%d' % (mode, i))
+        if mode == 'max':           # deterministic: the packed-key atomic max does not depend on arrival order
+            out2 = fn.apply(xg, tuple(ks), 0.01, *wb)
+            assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize('M,N,K,greedy', [(128, 10001, 512, 0), (5, 51, 64, 0), (37, 301, 96, 0), (128, 10001, 512, 1),
                                           (130, 20000, 64, 0), (256, 10001, 128, 0), (300, 777, 64, 1)])
 def test_proj_gumbel_fused(ops, M, N, K, greedy):

@@ -60,6 +60,9 @@ _SIGS = {
     'a4nt_proj_gumbel_fwd': (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_float, c_float, c_int, c_int, P, c_int,
                                      c_ulonglong, c_uint, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_longlong, P]),
     'a4nt_nll_rows': (c_int, [c_int, c_int, P, c_int, P, c_float, P, c_int, P]),
+    'a4nt_sgemm_nll_parts': (c_int, [c_int]),
+    'a4nt_sgemm_nll': (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
+    'a4nt_nll_grad_rows': (c_int, [c_int, c_int, P, c_int, P, P, c_int, c_float, P, c_int, P]),
     'a4nt_embed_fwd': (c_int, [c_longlong, c_int, c_int, P, P, P, P, c_int, P]),
     'a4nt_embed_bwd': (c_int, [c_longlong, c_int, c_int, P, P, P, c_int, P, c_longlong, P]),
     'a4nt_colsum': (c_int, [c_int, c_int, P, c_int, P, c_int, P]),

@@ -247,3 +247,63 @@ extern "C" int a4nt_nll_rows(int N, int V, float* logits, int ld, const long lon
                        loss_rows, write_grad);
     return a4nt_check_launch("nll_rows");
 }
+
+
+// Row kernel behind a4nt_sgemm_nll: merges the per-wave (max, sum exp) partials the projection's epilogue left for
+// the row, gives the row's loss and turns the logits into (softmax - onehot) * gscale in place: ONE read and one
+// write of the row; the loss itself costs no pass over the logits.  target < 0: row ignored (loss 0, gradient 0).
+__global__ __launch_bounds__(256) void nll_grad_rows_kernel(int V, float* logits, int ld, const long long* target,
+                                                            const float* part, int nparts, float gscale,
+                                                            float* loss_rows, int write_grad) {
+    __shared__ float red[ROWS_MAXW];
+    const int r = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    float* x = logits + (long long)r * ld;
+    const long long tg = target[r];
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
+    const int V4 = vec ? (V & ~3) : 0;
+    if (tg < 0) {
+        if (write_grad) {
+            for (int v = 4 * tid; v < V4; v += 4 * NT) *reinterpret_cast<f32x4*>(x + v) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int v = V4 + tid; v < V; v += NT) x[v] = 0.f;
+        }
+        if (tid == 0) loss_rows[r] = 0.f;
+        return;
+    }
+    const float* pr = part + (long long)r * nparts * 2;
+    float ml = -INFINITY;
+    for (int p = tid; p < nparts; p += NT) ml = fmaxf(ml, pr[2 * p]);
+    const float m = block_max(ml, red);
+    float sl = 0.f;
+    for (int p = tid; p < nparts; p += NT) {
+        const float mp = pr[2 * p];
+        if (mp != -INFINITY) sl += pr[2 * p + 1] * expf(mp - m);
+    }
+    const float s = block_sum(sl, red);
+    const float lse = m + logf(s);
+    if (tid == 0) loss_rows[r] = lse - x[tg];
+    if (write_grad) {
+        __syncthreads();                       // x[tg] is read above, overwritten below
+        const float inv = 1.0f / s;
+        for (int v = 4 * tid; v < V4; v += 4 * NT) {
+            f32x4 q = *reinterpret_cast<const f32x4*>(x + v);
+            q.x = (expf(q.x - m) * inv - ((long long)v == tg ? 1.f : 0.f)) * gscale;
+            q.y = (expf(q.y - m) * inv - ((long long)(v + 1) == tg ? 1.f : 0.f)) * gscale;
+            q.z = (expf(q.z - m) * inv - ((long long)(v + 2) == tg ? 1.f : 0.f)) * gscale;
+            q.w = (expf(q.w - m) * inv - ((long long)(v + 3) == tg ? 1.f : 0.f)) * gscale;
+            *reinterpret_cast<f32x4*>(x + v) = q;
+        }
+        for (int v = V4 + tid; v < V; v += NT) x[v] = (expf(x[v] - m) * inv - ((long long)v == tg ? 1.f : 0.f)) * gscale;
+    }
+}
+
+extern "C" int a4nt_nll_grad_rows(int N, int V, float* logits, int ld, const long long* target, const float* part,
+                                  int nparts, float gscale, float* loss_rows, int write_grad, void* stream) {
+    if (N <= 0) return A4NT_OK;
+    if (V <= 0 || !logits || !target || !part || !loss_rows || nparts != 2 * ((V + 127) / 128)) {
+        a4nt_set_error("a4nt_nll_grad_rows: bad arguments (V=%d, nparts=%d)", V, nparts);
+        return A4NT_ERR_ARG;
+    }
+    hipLaunchKernelGGL(nll_grad_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, V, logits, ld, target, part, nparts,
+                       gscale, loss_rows, write_grad);
+    return a4nt_check_launch("nll_grad_rows");
+}

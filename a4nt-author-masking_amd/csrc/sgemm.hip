@@ -34,6 +34,8 @@ struct GemmArgs {
     int kchunk;          // K range per blockIdx.z (multiple of BK)
     long long slab;      // C offset (floats) per blockIdx.z
     int tiles_n;
+    float* part;         // NLL epilogue: [M][nparts][2] per-row (max, sum exp) over each wave's 64 columns, or null
+    int nparts;
 };
 
 #include "gemm_stage.h"
@@ -96,7 +98,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kb
     }
 }
 
-template <bool TA, bool TB, int WM, int WN, int PF, int KG>
+template <bool TA, bool TB, int WM, int WN, int PF, int KG, bool NLL = false>
 __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int ASZ = BK * (BM + LPAD), BSZ = BK * (BN + LPAD);
@@ -172,13 +174,19 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
 
     // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const bool add_bias = (g.bias != nullptr) && (blockIdx.z == 0);
+    float bcol[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int col = n0 + wn + 32 * j + (lane & 31);
+        bcol[j] = (add_bias && col < g.N) ? g.bias[col] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int col = n0 + wn + 32 * j + (lane & 31);
             if (col >= g.N) continue;
-            const float bv = add_bias ? g.bias[col] : 0.f;
+            const float bv = bcol[j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -190,6 +198,38 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
                 }
             }
         }
+    if (NLL) {
+        // log-softmax statistics of the logits just produced, while they are still in the accumulators: per row the
+        // (max, sum of exp relative to it) over this wave's 32*WN columns.  A row of the 32x32 tile lives in one
+        // register index across the 32 lanes of a half wave: butterfly over those lanes.  The row kernel
+        // (a4nt_nll_grad_rows) merges the partials of a row, so the loss needs no pass of its own over the logits.
+        const int p = tn * 2 + (wave & 1);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v[WN];
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int col = n0 + wn + 32 * j + (lane & 31);
+                    v[j] = col < g.N ? acc[i][j][r] + bcol[j] : -INFINITY;
+                    m = fmaxf(m, v[j]);
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                float e = 0.f;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) e += (v[j] == -INFINITY) ? 0.f : expf(v[j] - m);
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) e += __shfl_xor(e, o);
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if ((lane & 31) == 0 && row < g.M) {
+                    float* q = g.part + ((long long)row * g.nparts + p) * 2;
+                    q[0] = m; q[1] = e;
+                }
+            }
+    }
 }
 
 template <bool TA, bool TB, int WM, int WN, int PF, int KG = 1>
@@ -282,9 +322,33 @@ extern "C" int a4nt_sgemm(int transA, int transB, int M, int N, int K, const flo
     g.kchunk = kchunk;
     g.slab = slab_stride;
     g.tiles_n = 0;
+    g.part = nullptr; g.nparts = 0;
     hipStream_t s = (hipStream_t)stream;
     const bool big = a4nt_sgemm_tile(M, N, ksplit) == 128;
     if (!transA && !transB) return big ? launch_sgemm<false, false, 2, 2, PFB>(g, ksplit, s) : launch_small<false, false>(g, ksplit, s);
     if (!transA && transB) return big ? launch_sgemm<false, true, 2, 2, PFB>(g, ksplit, s) : launch_small<false, true>(g, ksplit, s);
     return big ? launch_sgemm<true, false, 2, 2, PFB>(g, ksplit, s) : launch_small<true, false>(g, ksplit, s);
+}
+
+// Vocabulary projection with the log-softmax statistics in its epilogue (include/a4nt_hip.h).
+extern "C" int a4nt_sgemm_nll_parts(int N) { return N > 0 ? 2 * ((N + 127) / 128) : -1; }
+extern "C" int a4nt_sgemm_nll(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                              const float* bias, float* part, void* stream) {
+    if (M <= 0 || N <= 0) return A4NT_OK;
+    if (K <= 0 || !A || !B || !C || !part || lda < K || ldb < N || ldc < N) {
+        a4nt_set_error("a4nt_sgemm_nll: bad arguments (M=%d N=%d K=%d)", M, N, K);
+        return A4NT_ERR_ARG;
+    }
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.beta = 0;
+    g.kchunk = ((K + BK - 1) / BK) * BK;
+    g.slab = 0;
+    g.part = part; g.nparts = a4nt_sgemm_nll_parts(N);
+    constexpr int BM = 128, BN = 128;
+    const int tiles_m = (M + BM - 1) / BM;
+    g.tiles_n = (N + BN - 1) / BN;
+    hipLaunchKernelGGL((sgemm_kernel<false, false, 2, 2, PFB, 1, true>), dim3(tiles_m * g.tiles_n, 1, 1), dim3(256), 0,
+                       (hipStream_t)stream, g);
+    return a4nt_check_launch("sgemm_nll");
 }

@@ -796,11 +796,19 @@ class _ProjNLL(Function):
     def forward(ctx, h, W, b, target, n_valid):
         lib = _lib.load()
         N, V = h.shape[0], W.shape[1]
+        K = h.shape[1]
         logits = padded_rows(N, V, h.device)          # 16-byte aligned rows: vector loads in the backward GEMMs
-        gemm(h, W, bias=b, out=logits)
+        nparts = int(lib.a4nt_sgemm_nll_parts(V))
+        part = torch.empty((N, nparts, 2), device=h.device, dtype=torch.float32)
+        W2 = _rowmajor(_f32(W, 'proj_nll W'))
+        # projection whose epilogue leaves the per-row softmax statistics: the logits are written once ...
+        with _Timed('sgemm_nn_128' if TIMER is not None else None, 2.0 * N * V * K):
+            check(lib.a4nt_sgemm_nll(N, V, K, _p(h), _ld(h), _p(W2), _ld(W2), _p(logits), _ld(logits), _p(b), _p(part), _s()),
+                  'a4nt_sgemm_nll')
         loss_rows = torch.empty(N, device=h.device, dtype=torch.float32)
-        check(lib.a4nt_nll_rows(N, V, _p(logits), _ld(logits), _p(target), 1.0 / float(n_valid), _p(loss_rows), 1, _s()),
-              'a4nt_nll_rows')
+        # ... and read once: loss from the merged statistics, (softmax - onehot)/n_valid in place
+        check(lib.a4nt_nll_grad_rows(N, V, _p(logits), _ld(logits), _p(target), _p(part), nparts, 1.0 / float(n_valid),
+                                     _p(loss_rows), 1, _s()), 'a4nt_nll_grad_rows')
         ctx.save_for_backward(h, W, logits)
         return loss_rows.sum() / float(n_valid)
 

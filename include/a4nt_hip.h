@@ -205,12 +205,26 @@ int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh, const flo
                          long long* tok, float* val_in, float* val_out, int* gen_lens, unsigned char* done,
                          long long end_c, void* stream);
 
-/* Fused log-softmax + NLL over N rows; leaves (softmax - onehot)*gscale in place of the logits when
- * write_grad.  target < 0 ignores the row.
+/* Log-softmax + NLL over N rows of logits that some other producer wrote (no statistics available): leaves
+ * (softmax - onehot)*gscale in place of the logits when write_grad.  target < 0 ignores the row.
  * Replaces: nn.CrossEntropyLoss over packed scores (train_translator.py:112-113;
  * train_adversarial_translator.py:661-664) and its backward. */
 int a4nt_nll_rows(int N, int V, float* logits, int ld, const long long* target, float gscale, float* loss_rows,
                   int write_grad, void* stream);
+
+/* Fused output projection + log-softmax / NLL.  a4nt_sgemm_nll: C[M,N] = A[M,K] * B[K,N] + bias on 128x128 MFMA
+ * tiles whose epilogue, besides writing the logits once, reduces per row the (max, sum exp) of each wave's 64
+ * columns while they are still in the accumulators: part [M][a4nt_sgemm_nll_parts(N)][2].  a4nt_nll_grad_rows then
+ * merges a row's partials into its log-sum-exp, writes loss_rows[n] = lse - logit[target[n]] and, with write_grad,
+ * turns the row into (softmax - onehot) * gscale in place: one read and one write of the [M,N] logits in total, no
+ * pass of its own for the loss.  target < 0 ignores the row (loss 0, gradient 0).
+ * Replaces: dec_out.mm(decoder_W) + b -> nn.CrossEntropyLoss over the packed scores and its backward seed
+ * (char_translator.py:279-284; train_translator.py:112-113; train_adversarial_translator.py:661-664). */
+int a4nt_sgemm_nll_parts(int N);
+int a4nt_sgemm_nll(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   const float* bias, float* part, void* stream);
+int a4nt_nll_grad_rows(int N, int V, float* logits, int ld, const long long* target, const float* part, int nparts,
+                       float gscale, float* loss_rows, int write_grad, void* stream);
 
 /* Embedding gather out[n] = scale[n]*W[ids[n]] and its scatter-add backward (padding_idx row skipped).
  * Replaces: nn.Embedding lookups (char_translator.py:212,250,327,349,389; char_lstm.py:280;

@@ -348,21 +348,24 @@ def test_gumbel_philox_uniformity(ops):
     assert counts.min() > 0.6 * expected and counts.max() < 1.4 * expected
 
 
-def test_proj_nll(ops):
-    N, H, V = 37, 64, 301
-    h, W, b = _rand(N, H, seed=41), _rand(H, V, seed=42, scale=0.3), _rand(V, seed=43)
+@pytest.mark.parametrize('N,H,V,scale', [(37, 64, 301, 0.3), (300, 512, 10001, 0.05), (129, 100, 128, 0.3), (5, 33, 257, 8.0),
+                                         (260, 48, 64, 0.3)])
+def test_proj_nll(ops, N, H, V, scale):
+    """Projection with the log-softmax statistics in its epilogue + the row kernel that merges them
+    (a4nt_sgemm_nll + a4nt_nll_grad_rows) against F.cross_entropy(h W + b); scale 8: logits of magnitude ~100."""
+    h, W, b = _rand(N, H, seed=41), _rand(H, V, seed=42, scale=scale), _rand(V, seed=43)
     tgt = torch.randint(0, V, (N,), generator=torch.Generator().manual_seed(2))
-    tgt[5] = -1
-    tgt[20] = -1
-    hc, Wc, bc = (t.clone().requires_grad_(True) for t in (h, W, b))
+    tgt[N // 7] = -1
+    tgt[N // 2] = -1
+    hc, Wc, bc = (t.clone().double().requires_grad_(True) for t in (h, W, b))
     ref = F.cross_entropy(hc @ Wc + bc, tgt, ignore_index=-1)
     (ref * 1.7).backward()
     hg, Wg, bg = (t.cuda().requires_grad_(True) for t in (h, W, b))
     loss = ops.proj_nll(hg, Wg, bg, tgt.cuda(), int((tgt >= 0).sum()))
     (loss * 1.7).backward()
-    assert_close(loss, ref.detach(), TOL, 'nll loss')
+    assert_close(loss, ref.detach().float(), TOL, 'nll loss')
     for a, r, n in ((hg, hc, 'dh'), (Wg, Wc, 'dW'), (bg, bc, 'db')):
-        assert_close(a.grad, r.grad, TOLG, 'nll ' + n)
+        assert_close(a.grad, r.grad.float(), TOLG, 'nll ' + n)
 
 
 @pytest.mark.parametrize('K', [2, 3, 4, 5])

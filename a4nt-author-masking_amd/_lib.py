@@ -23,6 +23,28 @@ class LstmBwdProblem(ctypes.Structure):      # a4nt_lstm_bwd_problem
         'whh', 'gates', 'cs', 'c0', 'lens', 'dhs', 'dhN', 'dcN', 'dgates', 'dh0', 'dc0', 'xch', 'sync')]
 
 
+class GenFwdArgs(ctypes.Structure):          # a4nt_gen_fwd_args
+    _fields_ = [('B', c_int), ('H', c_int), ('V', c_int), ('n_max', c_int),
+                ('cg', c_void_p), ('ptab', c_void_p), ('tok0', c_void_p), ('ones', c_void_p), ('whh', c_void_p),
+                ('hs_all', c_void_p), ('gates', c_void_p), ('cs', c_void_p), ('xch', c_void_p),
+                ('W', c_void_p), ('ldw', c_int), ('bias', c_void_p), ('scale', c_float), ('tau', c_float),
+                ('hard', c_int), ('greedy', c_int),
+                ('U', POINTER(c_void_p)), ('n_noise', c_int), ('ldu', c_int),
+                ('seed', c_ulonglong), ('step0', c_uint),
+                ('z', c_void_p), ('ldz', c_int), ('zrow0', c_int), ('zrows', c_int),
+                ('part', c_void_p), ('stats', c_void_p), ('tok', c_void_p), ('val_in', c_void_p), ('val_out', c_void_p),
+                ('gen_lens', c_void_p), ('done', c_void_p), ('end_c', c_longlong)]
+
+
+class GenBwdArgs(ctypes.Structure):          # a4nt_gen_bwd_args
+    _fields_ = [('n', c_int), ('B', c_int), ('H', c_int), ('E', c_int), ('V', c_int),
+                ('S', c_void_p), ('lds', c_int), ('D', c_void_p), ('ldd', c_int), ('y', c_void_p), ('ldy', c_int),
+                ('stats', c_void_p), ('coef', c_float), ('inv_tau', c_float),
+                ('emb_W', c_void_p), ('W_out', c_void_p), ('ldw', c_int), ('Wcat', c_void_p),
+                ('gates', c_void_p), ('cs', c_void_p), ('dc', c_void_p), ('dG', c_void_p), ('rec', c_void_p),
+                ('dh_slabs', c_void_p), ('ks_v', c_int), ('rec_slabs', c_void_p), ('ks_r', c_int)]
+
+
 _SIGS = {
     'a4nt_last_error': (c_char_p, []),
     'a4nt_version': (c_int, []),
@@ -50,6 +72,8 @@ _SIGS = {
     'a4nt_lstm_seq_bwd_pair': (c_int, [c_int, POINTER(LstmBwdProblem), POINTER(LstmBwdProblem), P]),
     'a4nt_lstm_check_timeout': (c_int, [P, c_int, P]),
     'a4nt_lstm_dec_step': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
+    'a4nt_gen_loop_fwd': (c_int, [POINTER(GenFwdArgs), c_int, c_int, P]),
+    'a4nt_gen_loop_bwd': (c_int, [POINTER(GenBwdArgs), P]),
     'a4nt_lstm_cell_bwd': (c_int, [c_int, c_int, P, P, P, P, c_int, c_longlong, P, c_int, P, P, P]),
     'a4nt_gumbel_fwd': (c_int, [c_int, c_int, P, c_int, P, c_int, c_ulonglong, c_uint, c_float, c_float, c_int, c_int,
                                 P, c_int, P, P, P, P, P, P, c_longlong, P, c_int, P]),

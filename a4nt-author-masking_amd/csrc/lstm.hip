@@ -41,6 +41,15 @@
 
 #define PSTR 68   // LDS row stride (floats) of the partial gate tiles: conflict-free MFMA-layout stores
 
+// Block index -> (row group g, workgroup j of the group): g = bid % G, so the workgroups of a group share
+// blockIdx % 8 (one XCD under round-robin placement: speed only).  Measured (tools/micro/census.hip): with two
+// workgroups per CU, blocks b and b + 256 share a CU, i.e. two workgroups of the SAME group at G = 16; giving the
+// second one another group instead (and a half-step head start) was tried and is slower (bwd 10.1 -> 11.7 us/step).
+__device__ __forceinline__ void decode_bid(const int bid, const int G, int& g, int& j) {
+    g = bid % G;
+    j = bid / G;
+}
+
 struct LstmFwdArgs {
     int T, B, H, G, NW;
     const float* gx;        // [T][B][4H] input-gate pre-activations (biases included)
@@ -69,7 +78,8 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bi
     __shared__ __attribute__((aligned(16))) float hstage[MT][256];
     __shared__ int s_ok;
 
-    const int g = bid % a.G, j = bid / a.G;
+    int g, j;
+    decode_bid(bid, a.G, g, j);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H = a.H, H4 = 4 * a.H;
     constexpr int nj = NJ;                 // 16-wide k blocks in this wave's K quarter (H = 64*NJ)
@@ -320,7 +330,8 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a, const int bi
     __shared__ __attribute__((aligned(16))) float red[4][MT][16 * 20];  // per-wave partial sums [col][row]
     __shared__ int s_ok;
 
-    const int g = bid % a.G, j = bid / a.G;
+    int g, j;
+    decode_bid(bid, a.G, g, j);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H = a.H, H4 = 4 * a.H;
     const int u0 = 16 * j;
@@ -561,6 +572,257 @@ __global__ __launch_bounds__(256) void lstm_bwd2_kernel(LstmBwdArgs a, LstmBwdAr
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward sweep, 2-D decomposition (16 rows per group, H = 256 / 512 / 1024)
+// ---------------------------------------------------------------------------------------------
+// The NW = H/16 workgroups of a row group form a P x 4 grid: workgroup (i, q) holds the W_hh block
+// [4 gates x units 64i..64i+63][columns q*H/4 .. (q+1)*H/4) (again H/4 weight registers per lane).  Per step it
+//   * sums, for ITS 64 units, the P partial dh blocks the workgroups (., q*) of that column range published
+//     (wave w: unit tile 4i+w, P contiguous 1 KiB blocks; the sum lands in the lanes that own those
+//     (row, unit) pairs -- no LDS round trip),
+//   * runs the cell backward for its 16 rows x 64 units (4 pairs per thread; the 4 workgroups of a unit block do
+//     this redundantly: element-wise work on data that is prefetched a step ahead), dgates -> LDS [16][256],
+//   * multiplies that tile with its weight block: a partial dh over H/4 columns,
+//   * publishes it: 16 x H/4 floats per step instead of the 16 x H of the 1-D scheme (lstm_bwd_body), where every
+//     workgroup publishes a partial over ALL columns -- at H = 512 a quarter of the write-through bytes, 2 instead
+//     of 8 stores per wave to drain before the signal, and a quarter of the lines leaving L2.
+// Same hand-off protocol and buffers as lstm_bwd_body (block index differs); one arrival counter per group.
+template <int NT>   // NT = H / 256: 16-column tiles per wave
+__device__ __forceinline__ void lstm_bwd2d_body(const LstmBwdArgs& a, const int bid) {
+    constexpr int SA = 260;                                            // LDS row stride of the dgates tile
+    __shared__ __attribute__((aligned(16))) float sA[16 * SA];         // [row][gate*64 + unit]
+    __shared__ int s_ok;
+
+    int g, jw;
+    decode_bid(bid, a.G, g, jw);
+    const int i_blk = jw >> 2, q = jw & 3;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int H = a.H, H4 = 4 * a.H, P = a.H >> 6, NTILES = a.H >> 4;
+    const int u0 = 64 * i_blk;
+    const int r0 = g * 16;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int ul = 16 * w + (lane >> 2);          // this thread's unit inside the block ...
+    const int rj0 = 4 * (lane & 3);               // ... and its 4 rows rj0..rj0+3
+    const int col0 = q * (H >> 2) + w * 16 * NT;  // first output column of this wave
+
+    // B operands: wreg[c][kb][e] (lane n = fr, k quad fq), kb = gate*4 + unit sub-block:
+    //   W_hh[gate*H + u0 + 16*ub + 4*fq + e][col0 + 16*c + fr]
+    float wreg[NT][16][4];
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                wreg[c][kb][e] = a.whh[(long long)((kb >> 2) * H + u0 + 16 * (kb & 3) + 4 * fq + e) * H + col0 + 16 * c + fr];
+
+    unsigned* ctr = a.sync + 32 * g;
+    unsigned* tmo = a.tmo;
+    const unsigned blk_bytes = 256 * 4;
+    const long long x_par = (long long)a.G * NTILES * P * 256;         // floats per parity
+    __amdgpu_buffer_rsrc_t rs = make_rsrc(a.gxch, (unsigned)(2 * x_par * 4));
+
+    float dh_rec[4], dc_next[4];
+    int len_r[4];
+    int Tg = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rb = r0 + rj0 + j;
+        dh_rec[j] = 0.f; dc_next[j] = 0.f;
+        len_r[j] = (rb < a.B) ? (a.lens ? min(a.lens[rb], a.T) : a.T) : 0;
+    }
+    if (a.lens) {
+        for (int r = 0; r < 16; ++r) {
+            const int rb = r0 + r;
+            if (rb < a.B) Tg = max(Tg, min(a.lens[rb], a.T));
+        }
+    } else {
+        Tg = a.T;
+    }
+    // dgates of the steps no row of this group ran (each of the four workgroups of a unit block: one gate)
+    for (int t = Tg; t < a.T; ++t)
+        for (int idx = tid; idx < 16 * 64; idx += 256) {
+            const int row = idx >> 6, cc = idx & 63;
+            if (r0 + row < a.B) a.dgates[((long long)t * a.B + r0 + row) * H4 + q * H + u0 + cc] = 0.f;
+        }
+
+    // Step inputs come through buffer loads: ONE per-thread byte offset per array (row rj0 of the thread, its unit)
+    // plus a wave-uniform offset per (row j, gate) in an SGPR -- no 64-bit address arithmetic, no per-load address
+    // registers; rows past the batch or a step before 0 fall outside the descriptor and read as 0 (never used).
+    struct StepIn { float ig, fg, gg, og, cp, dhs; };
+    StepIn cur[4];
+    float ct_cur[4];
+    const long long g_bytes = (long long)a.T * a.B * H4 * 4, c_bytes = (long long)a.T * a.B * H * 4;
+    __amdgpu_buffer_rsrc_t rg = make_rsrc(a.gates, (unsigned)min(g_bytes, 0xffffffffll));
+    __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cs, (unsigned)min(c_bytes, 0xffffffffll));
+    __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dhs ? a.dhs : a.cs, a.dhs ? (unsigned)min(c_bytes, 0xffffffffll) : 0u);
+    __amdgpu_buffer_rsrc_t r0c = make_rsrc(a.c0 ? a.c0 : a.cs, a.c0 ? (unsigned)((long long)a.B * H * 4) : 0u);
+    const unsigned thr_g = (unsigned)(((r0 + rj0) * H4 + u0 + ul) * 4);      // + t * B * 4H * 4
+    const unsigned thr_c = (unsigned)(((r0 + rj0) * H + u0 + ul) * 4);       // + t * B * H * 4
+    const unsigned step_g = (unsigned)(a.B * H4 * 4), step_c = (unsigned)(a.B * H * 4);
+    auto ldf = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+    };
+    auto load_step = [&](int t) {
+        const unsigned og_ = thr_g + (unsigned)t * step_g;          // t = -1 wraps far outside the descriptor: zeros
+        const unsigned oc_ = thr_c + (unsigned)t * step_c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cur[j].ig = ldf(rg, og_, (unsigned)((j * H4) * 4));
+            cur[j].fg = ldf(rg, og_, (unsigned)((j * H4 + H) * 4));
+            cur[j].gg = ldf(rg, og_, (unsigned)((j * H4 + 2 * H) * 4));
+            cur[j].og = ldf(rg, og_, (unsigned)((j * H4 + 3 * H) * 4));
+            if (t > 0) cur[j].cp = ldf(rc, oc_ - step_c, (unsigned)(j * H * 4));
+            else cur[j].cp = ldf(r0c, thr_c, (unsigned)(j * H * 4));             // c0 (null: empty descriptor -> 0)
+            cur[j].dhs = ldf(rd, oc_, (unsigned)(j * H * 4));
+        }
+    };
+    load_step(Tg - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        ct_cur[j] = Tg > 0 ? ldf(rc, thr_c + (unsigned)(Tg - 1) * step_c, (unsigned)(j * H * 4)) : 0.f;
+
+    // L2 warm-up of the step after next: one dword per 128-B line of the 16 rows x {4 gates, c_prev, dhs} x 64 units
+    // this workgroup will read two steps from now (192 lines, one per thread), issued at the top of a step so that
+    // it lands under the cell backward and the MFMA chain.  The loads of a wave return in order, and the loads of
+    // the peers' partial dh -- the hand-off's critical path -- must not queue behind HBM latency: the real inputs
+    // (load_step) are therefore issued AFTER them and find their lines in L2.
+    const int t_row = tid / 12, t_arr = (tid % 12) >> 1, t_half = tid & 1;
+    const unsigned tch_g = (unsigned)(((r0 + t_row) * H4 + (t_arr < 4 ? t_arr : 0) * H + u0 + 32 * t_half) * 4);
+    const unsigned tch_c = (unsigned)(((r0 + t_row) * H + u0 + 32 * t_half) * 4);
+    auto touch = [&](int t) -> float {
+        if (tid >= 192 || t < 0) return 0.f;
+        if (t_arr < 4) return ldf(rg, tch_g + (unsigned)t * step_g, 0u);
+        if (t_arr == 4) return ldf(rc, tch_c + (unsigned)(t - 1) * step_c, 0u);
+        return ldf(rd, tch_c + (unsigned)t * step_c, 0u);
+    };
+    float junk = 0.f, touched = 0.f;
+
+    int s = 0;
+    STAMP_DECL
+    for (int t = Tg - 1; t >= 0; --t, ++s) {
+        const int par = s & 1;
+        STAMP_BEGIN();
+        junk += touched;                      // (consumes the previous step's warm-up load: it landed long ago)
+        touched = touch(t - 2);
+        // (a) cell backward of this thread's 4 (row, unit) pairs -> dgates tile in LDS
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rb = r0 + rj0 + j;
+            float dp[4] = {0.f, 0.f, 0.f, 0.f};
+            if (rb < a.B && t < len_r[j]) {
+                const float ig = cur[j].ig, fg = cur[j].fg, gg = cur[j].gg, og = cur[j].og;
+                const float ct = ct_cur[j], cp = cur[j].cp;
+                float dh = dh_rec[j] + cur[j].dhs;
+                float dc = dc_next[j];
+                if (t == len_r[j] - 1) {
+                    if (a.dhN) dh += a.dhN[(long long)rb * H + u0 + ul];
+                    if (a.dcN) dc += a.dcN[(long long)rb * H + u0 + ul];
+                }
+                const float tc = tanhf_(ct);
+                dc += dh * og * (1.f - tc * tc);
+                dp[0] = dc * gg * ig * (1.f - ig);
+                dp[1] = dc * cp * fg * (1.f - fg);
+                dp[2] = dc * ig * (1.f - gg * gg);
+                dp[3] = dh * tc * og * (1.f - og);
+                dc_next[j] = dc * fg;
+            }
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) sA[(rj0 + j) * SA + gt * 64 + ul] = dp[gt];
+            ct_cur[j] = cur[j].cp;
+        }
+        __syncthreads();
+        if (t == 0 && !a.need_dh0) {
+            for (int idx = tid; idx < 16 * 64; idx += 256) {
+                const int row = idx >> 6, cc = idx & 63;
+                if (r0 + row < a.B) a.dgates[((long long)(r0 + row)) * H4 + q * H + u0 + cc] = sA[row * SA + q * 64 + cc];
+            }
+            break;
+        }
+        STAMP(0);
+        // (b) partial dh_{t-1}[:, this wave's 16*NT columns] = dgates tile [16 x 256] * weight block
+        f32x4 acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(&sA[fr * SA + (kb >> 2) * 64 + 16 * (kb & 3) + 4 * fq]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], wreg[c][kb][e], acc[c], 0, 0, 0);
+        }
+        // publish: block (column tile, producer unit block), [col][row] fragment order, one 1 KiB store per tile
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int ctg = (col0 >> 4) + c;
+            const long long blk = (((long long)par * a.G + g) * NTILES + ctg) * P + i_blk;
+            st16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + 4 * fq) * 4), acc[c]);
+        }
+        STAMP(1);
+        drain_vmem();
+        __syncthreads();
+        if (tid == 0) add_flag(ctr, 1u);
+        STAMP(2);
+        // dgates_t for the time-batched weight-gradient GEMMs (nobody waits for it inside this launch): the four
+        // workgroups that share the unit block write one gate each
+        for (int idx = tid; idx < 16 * 64; idx += 256) {
+            const int row = idx >> 6, cc = idx & 63;
+            if (r0 + row < a.B) a.dgates[((long long)t * a.B + r0 + row) * H4 + q * H + u0 + cc] = sA[row * SA + q * 64 + cc];
+        }
+        STAMP(3);
+        if (tid == 0) s_ok = wait_ge(ctr, (unsigned)(a.NW * (s + 1)), tmo) ? 1 : 0;
+        __syncthreads();
+        if (!s_ok) break;
+        STAMP(4);
+        // (c) dh_{t-1} of this wave's unit tile: sum of the P producers' blocks (contiguous), in producer order
+        f32x4 ps = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const long long base = (((long long)par * a.G + g) * NTILES + (u0 >> 4) + w) * P;
+            if (P == 4 * NT) {                   // (always: P = H/64 = 4*NT; spelled out so that the loads are all issued first)
+                f32x4 v[4 * NT];
+#pragma unroll
+                for (int p = 0; p < 4 * NT; ++p) v[p] = ld16_sc1(rs, (unsigned)((base + p) * blk_bytes + lane * 16));
+                // the next step's inputs, queued BEHIND the partial loads (warm in L2 since the step before last)
+                load_step(t - 1);
+#pragma unroll
+                for (int p = 0; p < 4 * NT; ++p) { ps.x += v[p].x; ps.y += v[p].y; ps.z += v[p].z; ps.w += v[p].w; }
+            }
+        }
+        dh_rec[0] = ps.x; dh_rec[1] = ps.y; dh_rec[2] = ps.z; dh_rec[3] = ps.w;
+        STAMP_WAITV();
+        STAMP(5);
+        // the barrier after the next (a) orders these steps' LDS reads before sA is rewritten: (a) writes sA, and every
+        // wave passed the barrier above only after all MFMA reads of sA (they precede the publish)
+    }
+
+    STAMP_FLUSH(a.sync, a.G);
+    if (junk == 123.456f && a.T < 0) a.dgates[0] = junk;       // keeps the warm-up loads alive; never true
+    if (q == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rb = r0 + rj0 + j;
+            if (rb < a.B) {
+                if (a.dh0) a.dh0[(long long)rb * H + u0 + ul] = dh_rec[j];
+                if (a.dc0) a.dc0[(long long)rb * H + u0 + ul] = dc_next[j];
+            }
+        }
+    }
+}
+
+// (second launch bound = waves per SIMD the register allocation must leave room for: two row groups per CU
+// up to H = 512, whose hand-off latencies then hide behind each other's MFMA phase)
+template <int NT>
+__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void lstm_bwd2d_kernel(LstmBwdArgs a) { lstm_bwd2d_body<NT>(a, blockIdx.x); }
+
+template <int NT>
+__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void lstm_bwd2d2_kernel(LstmBwdArgs a, LstmBwdArgs b, int nA) {
+    const bool first = (int)blockIdx.x < nA;
+    const LstmBwdArgs s = first ? a : b;
+    lstm_bwd2d_body<NT>(s, first ? (int)blockIdx.x : (int)blockIdx.x - nA);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 // Workgroup budget of one sweep.  256 = one workgroup per CU.  The MT = 1 kernels up to H = 512 fit two
@@ -646,14 +908,27 @@ template <typename KF, typename KB> static int occ_pair(KF kf, KB kb) {
         g_resident[device][1][ilog2(mt)][ilog2(nj)] = o * num_cus;                                                \
     } while (0)
 static int scratch_lookup(int device);
+#define A4NT_COMMA ,
+#define A4NT_PROBE_K(mt, nj, pair, KF, KB)                                                                        \
+    do {                                                                                                          \
+        const int o = occ_pair(KF, KB);                                                                           \
+        if (o < 1) { a4nt_set_error("a4nt_init: LSTM sweep <MT=%d,NJ=%d> cannot be resident on device %d (occupancy %d)", mt, nj, device, o); return A4NT_ERR_ARG; } \
+        g_resident[device][pair][ilog2(mt)][ilog2(nj)] = o * num_cus;                                             \
+    } while (0)
 int a4nt_lstm_probe_occupancy(int device, int num_cus) {
     if (device < 0 || device >= A4NT_MAX_DEV) return A4NT_OK;        // beyond the table: static caps
     const int rcs = scratch_lookup(device);                          // a4nt_lstm_seq_fwd_noalloc's per-device buffer
     if (rcs != A4NT_OK) return rcs;
-    A4NT_PROBE(1, 1); A4NT_PROBE(1, 2); A4NT_PROBE(1, 4); A4NT_PROBE(1, 8); A4NT_PROBE(1, 16);
+    A4NT_PROBE(1, 1); A4NT_PROBE(1, 2);
+    // 16 rows per group at H >= 256: the backward sweep is the 2-D kernel
+    A4NT_PROBE_K(1, 4, 0, lstm_fwd_kernel<1 A4NT_COMMA 4>, lstm_bwd2d_kernel<1>);
+    A4NT_PROBE_K(1, 8, 0, lstm_fwd_kernel<1 A4NT_COMMA 8>, lstm_bwd2d_kernel<2>);
+    A4NT_PROBE_K(1, 16, 0, lstm_fwd_kernel<1 A4NT_COMMA 16>, lstm_bwd2d_kernel<4>);
     A4NT_PROBE(2, 1); A4NT_PROBE(2, 2); A4NT_PROBE(2, 4); A4NT_PROBE(2, 8); A4NT_PROBE(2, 16);
     A4NT_PROBE(4, 1); A4NT_PROBE(4, 2); A4NT_PROBE(4, 4); A4NT_PROBE(4, 8); A4NT_PROBE(4, 16);
-    A4NT_PROBE2(1, 1); A4NT_PROBE2(1, 2); A4NT_PROBE2(1, 4); A4NT_PROBE2(1, 8);
+    A4NT_PROBE2(1, 1); A4NT_PROBE2(1, 2);
+    A4NT_PROBE_K(1, 4, 1, lstm_fwd2_kernel<1 A4NT_COMMA 4>, lstm_bwd2d2_kernel<1>);
+    A4NT_PROBE_K(1, 8, 1, lstm_fwd2_kernel<1 A4NT_COMMA 8>, lstm_bwd2d2_kernel<2>);
     A4NT_PROBE2(2, 1); A4NT_PROBE2(2, 2); A4NT_PROBE2(2, 4); A4NT_PROBE2(2, 8);
     return A4NT_OK;
 }
@@ -817,7 +1092,10 @@ extern "C" int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const fl
     a.dgates = dgates; a.dh0 = dh0; a.dc0 = dc0; a.gxch = xch; a.sync = sync; a.tmo = sync + 32 * G;
     a.need_dh0 = (dh0 != nullptr) ? 1 : 0;
     dim3 grid(G * a.NW), block(256);
-    A4NT_DISPATCH_LSTM(lstm_bwd_kernel, mt, H / 64, grid, block, s, a);
+    if (mt == 1 && H == 256) hipLaunchKernelGGL((lstm_bwd2d_kernel<1>), grid, block, 0, s, a);
+    else if (mt == 1 && H == 512) hipLaunchKernelGGL((lstm_bwd2d_kernel<2>), grid, block, 0, s, a);
+    else if (mt == 1 && H == 1024) hipLaunchKernelGGL((lstm_bwd2d_kernel<4>), grid, block, 0, s, a);
+    else A4NT_DISPATCH_LSTM(lstm_bwd_kernel, mt, H / 64, grid, block, s, a);
     return a4nt_check_launch("lstm_seq_bwd");
 }
 
@@ -916,6 +1194,8 @@ extern "C" int a4nt_lstm_seq_bwd_pair(int H, const a4nt_lstm_bwd_problem* p0, co
     }
     const int nA = G[0] * (H / 16);
     dim3 grid((G[0] + G[1]) * (H / 16)), block(256);
-    A4NT_DISPATCH_LSTM2(lstm_bwd2_kernel, mt, H / 64, grid, block, s, a[0], a[1], nA);
+    if (mt == 1 && H == 256) hipLaunchKernelGGL((lstm_bwd2d2_kernel<1>), grid, block, 0, s, a[0], a[1], nA);
+    else if (mt == 1 && H == 512) hipLaunchKernelGGL((lstm_bwd2d2_kernel<2>), grid, block, 0, s, a[0], a[1], nA);
+    else A4NT_DISPATCH_LSTM2(lstm_bwd2_kernel, mt, H / 64, grid, block, s, a[0], a[1], nA);
     return a4nt_check_launch("lstm_seq_bwd_pair");
 }

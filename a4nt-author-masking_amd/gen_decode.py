@@ -24,6 +24,17 @@ from .ops import gemm, gemm_auto, slab_reduce, colsum, embed_fwd, embed_bwd
 
 CHECK_EVERY = 16
 PACK_W = True             # re-lay the output projection out for the fused kernel once per generation
+# kernel labels of ops.TIMER that live inside the two loops: when bench.py times one of them the loops are driven
+# from Python (per-launch events); otherwise from the library's C++ loops (a4nt_gen_loop_fwd / _bwd): same kernels,
+# same order, a fraction of the host time per launch
+_LOOP_LABELS = ('proj_gumbel', 'sgemm_nt_64', 'sgemm_nn_64', 'sgemm_nt_rows', 'skinny_nn', 'skinny_nt')
+
+
+PY_LOOPS = False          # benchmarks: drive the loops from Python even when nothing is being timed
+
+
+def _native_loops():
+    return not PY_LOOPS and (ops.TIMER is None or ops.TIMER['name'] not in _LOOP_LABELS)
 
 
 class _GenHandle(object):
@@ -215,23 +226,52 @@ class _GenDecode(Function):
         s = ops._s()
         ran = 0
         pending = None
-        for t in range(n_max):
-            tk = tok0 if t == 0 else tok[t - 1]
-            vl = ones if t == 0 else val_in[t - 1]
-            cp = None if t == 0 else cs[t - 1]
-            _lib.check(lib.a4nt_lstm_dec_step(t, B, H, ops._p(cg), ops._p(ptab), ops._p(tk), ops._p(vl), ops._p(w_hh_c),
-                                              ops._p(cp), ops._p(hs_all[t + 1]), ops._p(gates[t]), ops._p(cs[t]),
-                                              ops._p(xch), s), 'a4nt_lstm_dec_step')
-            U = None
-            if noise is not None and not greedy and t < len(noise):
-                U = noise[t].contiguous()      # injected uniforms (parity tests); Philox beyond the list
+        seed, step0 = int(cfg.get('seed', 0)), int(cfg.get('step0', 0))
+        U_list = None
+        if noise is not None and not greedy:
+            U_list = [u.contiguous() for u in noise[:n_max]]     # injected uniforms (parity tests); Philox beyond the list
+            for U in U_list:
                 assert tuple(U.shape) == (B, V)
-            ops.proj_gumbel(hs_all[t + 1], W_out, b_out, U, cfg.get('seed', 0), cfg.get('step0', 0) + t, cfg['scale'],
-                            cfg['tau'], cfg['hard'], greedy, ybuf[t] if need_grad else None, part,
-                            stats[t], tok[t], val_in[t], val_out[t], gen_lens, done, cfg['end_c'], zrow0=r0,
-                            packed=W_packed)
-            ran = t + 1
-            if cfg['end_c'] >= 0 and (ran % CHECK_EVERY == 0) and ran < n_max:
+        native = _native_loops()
+        if native:
+            import ctypes
+            fa = _lib.GenFwdArgs()
+            fa.B, fa.H, fa.V, fa.n_max = B, H, V, n_max
+            fa.cg, fa.ptab, fa.tok0, fa.ones, fa.whh = ops._p(cg), ops._p(ptab), ops._p(tok0), ops._p(ones), ops._p(w_hh_c)
+            fa.hs_all, fa.gates, fa.cs, fa.xch = ops._p(hs_all), ops._p(gates), ops._p(cs), ops._p(xch)
+            Wk = W_out if W_packed is None else W_packed
+            if W_packed is None:
+                Wk = ops._rowmajor(W_out)
+            fa.W, fa.ldw, fa.bias = ops._p(Wk), (ops._ld(Wk) if W_packed is None else 0), ops._p(b_out)
+            fa.scale, fa.tau, fa.hard, fa.greedy = float(cfg['scale']), float(cfg['tau']), int(cfg['hard']), int(greedy)
+            if U_list:
+                arr = (ctypes.c_void_p * len(U_list))(*[u.data_ptr() for u in U_list])
+                fa.U, fa.n_noise, fa.ldu = arr, len(U_list), V
+            else:
+                fa.U, fa.n_noise, fa.ldu = None, 0, 0
+            fa.seed, fa.step0 = seed, step0
+            fa.z, fa.ldz, fa.zrow0, fa.zrows = (ops._p(ybuf), V, r0, r1 - r0) if need_grad else (None, 0, r0, 0)
+            fa.part, fa.stats, fa.tok, fa.val_in, fa.val_out = ops._p(part), ops._p(stats), ops._p(tok), ops._p(val_in), ops._p(val_out)
+            fa.gen_lens, fa.done, fa.end_c = ops._p(gen_lens), ops._p(done), int(cfg['end_c'])
+        chunk = n_max if cfg['end_c'] < 0 else CHECK_EVERY
+        for c0 in range(0, n_max, chunk):
+            c1 = min(n_max, c0 + chunk)
+            if native:
+                _lib.check(lib.a4nt_gen_loop_fwd(ctypes.byref(fa), c0, c1, s), 'a4nt_gen_loop_fwd')
+            else:
+                for t in range(c0, c1):
+                    tk = tok0 if t == 0 else tok[t - 1]
+                    vl = ones if t == 0 else val_in[t - 1]
+                    cp = None if t == 0 else cs[t - 1]
+                    _lib.check(lib.a4nt_lstm_dec_step(t, B, H, ops._p(cg), ops._p(ptab), ops._p(tk), ops._p(vl),
+                                                      ops._p(w_hh_c), ops._p(cp), ops._p(hs_all[t + 1]), ops._p(gates[t]),
+                                                      ops._p(cs[t]), ops._p(xch), s), 'a4nt_lstm_dec_step')
+                    U = U_list[t] if (U_list is not None and t < len(U_list)) else None
+                    ops.proj_gumbel(hs_all[t + 1], W_out, b_out, U, seed, step0 + t, cfg['scale'], cfg['tau'], cfg['hard'],
+                                    greedy, ybuf[t] if need_grad else None, part, stats[t], tok[t], val_in[t], val_out[t],
+                                    gen_lens, done, cfg['end_c'], zrow0=r0, packed=W_packed)
+            ran = c1
+            if cfg['end_c'] >= 0 and ran < n_max:
                 # "all sentences ended?" is read one period late: the answer asked for CHECK_EVERY steps ago has
                 # long arrived, so the host never waits for the GPU to drain (steps run past the end are trimmed
                 # below, as the steps between two checks already were)
@@ -322,22 +362,36 @@ class _GenDecode(Function):
         ks_r = max(1, ops._auto_ksplit(B, H + E, 4 * H))
         dh_slabs = torch.empty((ks_v, B, H), device=dev)
         rec_slabs = torch.empty((ks_r, B, H + E), device=dev) if ks_r > 1 else None
-        for t in range(n - 1, -1, -1):
-            if t < n - 1:
-                gemm(rec[t + 1][:, H:], emb_W, transB=True, out=S[t], beta=1)      # += d(emb_{t+1}) * E^T
-            ops.gumbel_bwd_rows(S[t], ybuf[t], stats[t], coef, 1.0 / float(cfg['tau']), out=D[t])   # dlogits_t
-            gemm(D[t], W_out, transB=True, out=dh_slabs if ks_v > 1 else dh_slabs[0], ksplit=ks_v)
-            _lib.check(lib.a4nt_lstm_cell_bwd(B, H, ops._p(gates[t]), ops._p(cs[t]), ops._p(cs[t - 1] if t > 0 else None),
-                                              ops._p(dh_slabs), ks_v, B * H,
-                                              ops._p(rec[t + 1]) if t < n - 1 else None, H + E,
-                                              ops._p(dc), ops._p(dG[t]), s), 'a4nt_lstm_cell_bwd')
-            if ks_r > 1:
-                gemm(dG[t], Wcat, out=rec_slabs, ksplit=ks_r)
-                lib_rc = lib.a4nt_slab_reduce(ks_r, B * (H + E), B, H + E, ops._p(rec_slabs), H + E, 0, None, 0,
-                                              ops._p(rec[t]), H + E, s)
-                _lib.check(lib_rc, 'a4nt_slab_reduce')
-            else:
-                gemm(dG[t], Wcat, out=rec[t])
+        if _native_loops():
+            import ctypes
+            ba = _lib.GenBwdArgs()
+            emb_c, Wo_c = ops._rowmajor(emb_W), ops._rowmajor(W_out)
+            ba.n, ba.B, ba.H, ba.E, ba.V = n, B, H, E, V
+            ba.S, ba.lds, ba.D, ba.ldd = ops._p(S2), ops._ld(S2), ops._p(D2), ops._ld(D2)
+            ba.y, ba.ldy, ba.stats = ops._p(ybuf), V, ops._p(stats)
+            ba.coef, ba.inv_tau = coef, 1.0 / float(cfg['tau'])
+            assert ops._ld(emb_c) == E and ybuf.is_contiguous() and stats.is_contiguous() and gates.is_contiguous() and cs.is_contiguous()
+            ba.emb_W, ba.W_out, ba.ldw, ba.Wcat = ops._p(emb_c), ops._p(Wo_c), ops._ld(Wo_c), ops._p(Wcat)
+            ba.gates, ba.cs, ba.dc, ba.dG, ba.rec = ops._p(gates), ops._p(cs), ops._p(dc), ops._p(dG), ops._p(rec)
+            ba.dh_slabs, ba.ks_v, ba.rec_slabs, ba.ks_r = ops._p(dh_slabs), ks_v, ops._p(rec_slabs), ks_r
+            _lib.check(lib.a4nt_gen_loop_bwd(ctypes.byref(ba), s), 'a4nt_gen_loop_bwd')
+        else:
+            for t in range(n - 1, -1, -1):
+                if t < n - 1:
+                    gemm(rec[t + 1][:, H:], emb_W, transB=True, out=S[t], beta=1)      # += d(emb_{t+1}) * E^T
+                ops.gumbel_bwd_rows(S[t], ybuf[t], stats[t], coef, 1.0 / float(cfg['tau']), out=D[t])   # dlogits_t
+                gemm(D[t], W_out, transB=True, out=dh_slabs if ks_v > 1 else dh_slabs[0], ksplit=ks_v)
+                _lib.check(lib.a4nt_lstm_cell_bwd(B, H, ops._p(gates[t]), ops._p(cs[t]), ops._p(cs[t - 1] if t > 0 else None),
+                                                  ops._p(dh_slabs), ks_v, B * H,
+                                                  ops._p(rec[t + 1]) if t < n - 1 else None, H + E,
+                                                  ops._p(dc), ops._p(dG[t]), s), 'a4nt_lstm_cell_bwd')
+                if ks_r > 1:
+                    gemm(dG[t], Wcat, out=rec_slabs, ksplit=ks_r)
+                    lib_rc = lib.a4nt_slab_reduce(ks_r, B * (H + E), B, H + E, ops._p(rec_slabs), H + E, 0, None, 0,
+                                                  ops._p(rec[t]), H + E, s)
+                    _lib.check(lib_rc, 'a4nt_slab_reduce')
+                else:
+                    gemm(dG[t], Wcat, out=rec[t])
         demb_all = rec[:, :, H:].contiguous()
         dG2 = dG.view(n * B, 4 * H)
         d_W_out = gemm_auto(hs_all[1:n + 1].reshape(n * B, H), D2, transA=True)

@@ -46,8 +46,17 @@ class _Timed(object):
 
     def __enter__(self):
         if self.on:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
+            pool = TIMER.get('pool')
+            if pool is not None:
+                # events made before the timed region (creating them inside it costs host time per launch); when the
+                # pool runs dry the remaining launches go untimed
+                if len(pool) < 2:
+                    self.on = False
+                    return self
+                self.e0, self.e1 = pool.pop(), pool.pop()
+            else:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
@@ -56,6 +65,14 @@ class _Timed(object):
             self.e1.record()
             TIMER['events'].append((self.e0, self.e1, self.flops))
         return False
+
+
+def make_timer(name, max_launches=None):
+    """TIMER dictionary for kernel label `name`; max_launches pre-creates that many event pairs."""
+    t = {'name': name, 'events': []}
+    if max_launches:
+        t['pool'] = [torch.cuda.Event(enable_timing=True) for _ in range(2 * int(max_launches))]
+    return t
 
 
 def _rowmajor(t):

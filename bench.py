@@ -189,8 +189,12 @@ def main():
     ap.add_argument('--roofline-kernel', default='sgemm_nt_128',
                     help='kernel timed with HIP events inside the timed region (default: the kernel with the '
                          'largest share of the step in profiles/: sgemm_kernel<false,true,2,2,2>)')
+    ap.add_argument('--timed-launches', type=int, default=1024,
+                    help='HIP event pairs made before the timed region for the roofline kernel (launches beyond go untimed)')
     ap.add_argument('--no-extra-rooflines', action='store_true')
     ap.add_argument('--no-pack-w', action='store_true', help='fused projection reads the [H,V] matrix as stored')
+    ap.add_argument('--py-loops', action='store_true',
+                    help='drive the decoder\'s step loops from Python instead of the library\'s C++ loops (A/B)')
     ap.add_argument('--lstm-workgroups', type=int, default=0, choices=(0, 256, 512),
                     help='persistent LSTM sweep residency (0: 512 on one GPU, 256 beside RCCL kernels when N > 1)')
     args = ap.parse_args()
@@ -210,6 +214,9 @@ def main():
     if args.no_pack_w:
         from a4nt_amd import gen_decode
         gen_decode.PACK_W = False
+    if args.py_loops:
+        from a4nt_amd import gen_decode
+        gen_decode.PY_LOOPS = True
     if args.lstm_workgroups:
         impl.lstm_set_max_workgroups(args.lstm_workgroups)
     elif world > 1:
@@ -254,7 +261,7 @@ def main():
     for it in range(args.warmup):
         run_step(it, reducers)
     ops.check_timeouts()
-    ops.TIMER = {'name': args.roofline_kernel, 'events': []}
+    ops.TIMER = ops.make_timer(args.roofline_kernel, max_launches=args.timed_launches)
     sync()
     t0 = time.perf_counter()
     for it in range(args.steps):

@@ -161,6 +161,41 @@ int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const float* pta
                        const float* val, const float* whh, const float* c_prev, float* h_out, float* gates_out,
                        float* c_out, float* xch, void* stream);
 
+/* The free-running decoder's host loops in native code: steps [t0, t1) of the generation loop
+ * (a4nt_lstm_dec_step + a4nt_proj_gumbel_fwd per step) and the whole reverse loop of its backward pass (per step,
+ * last to first: S_t += d(emb_{t+1}) E^T; a4nt_gumbel_bwd; dlogits_t W_out^T in ks_v split-K slabs;
+ * a4nt_lstm_cell_bwd; dgates_t [W_hh | W_ie] in ks_r slabs + a4nt_slab_reduce).  Exactly the kernel sequence the
+ * per-step entry points give, issued from a C++ loop (about 3 us of host time per launch instead of the 10-20 us a
+ * Python wrapper costs: 900 launches per training step), on `stream`; nothing is allocated or synchronised.
+ * All arrays are the caller's, time major and contiguous unless a leading dimension is given:
+ *   forward : hs_all [n_max+1][B][H] (row 0 = zeros), gates [n_max][B][4H], cs [n_max][B][H], stats [n_max][B][2],
+ *             tok / val_in / val_out [n_max][B], z [n_max][zrows][ldz] or NULL, U = host array of n_noise device
+ *             pointers ([B][ldu] uniforms per step) or NULL; the other fields as in a4nt_lstm_dec_step /
+ *             a4nt_proj_gumbel_fwd
+ *   backward: S, D [n][B][lds / ldd] (d(sample) in, dlogits out), y [n][B][ldy], rec [n][B][H+E] (out),
+ *             dG [n][B][4H] (out), dc [B][H] (zeros in), dh_slabs [ks_v][B][H], rec_slabs [ks_r][B][H+E] scratch
+ * Replaces: the Python-level loop of models/char_translator.py:375-399 and autograd's walk back through it. */
+typedef struct {
+    int B, H, V, n_max;
+    const float* cg; const float* ptab; const long long* tok0; const float* ones; const float* whh;
+    float* hs_all; float* gates; float* cs; float* xch;
+    const float* W; int ldw; const float* bias; float scale, tau; int hard, greedy;
+    const float* const* U; int n_noise, ldu;
+    unsigned long long seed; unsigned step0;
+    float* z; int ldz, zrow0, zrows;
+    float* part; float* stats; long long* tok; float* val_in; float* val_out; int* gen_lens; unsigned char* done;
+    long long end_c;
+} a4nt_gen_fwd_args;
+typedef struct {
+    int n, B, H, E, V;
+    float* S; int lds; float* D; int ldd; const float* y; int ldy; const float* stats; float coef, inv_tau;
+    const float* emb_W; const float* W_out; int ldw; const float* Wcat;
+    const float* gates; const float* cs; float* dc; float* dG; float* rec;
+    float* dh_slabs; int ks_v; float* rec_slabs; int ks_r;
+} a4nt_gen_bwd_args;
+int a4nt_gen_loop_fwd(const a4nt_gen_fwd_args* a, int t0, int t1, void* stream);
+int a4nt_gen_loop_bwd(const a4nt_gen_bwd_args* a, void* stream);
+
 /* Element-wise cell backward of one decoder step (reverse loop of the generator):
  * dh = sum of n_slabs split-K partials [B][H] (slab_stride floats apart) + dh_b [B][ldb] (may be NULL). */
 int a4nt_lstm_cell_bwd(int B, int H, const float* gates, const float* c_t, const float* c_prev, const float* dh_slabs,

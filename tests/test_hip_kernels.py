@@ -262,11 +262,18 @@ def test_lstm_paired_equals_sequential(ops, H, B0, B1, T0, T1, wgs):
             ops.check_timeouts()
             res[mode] = [la_.detach(), lb_.detach(), xa.grad, xb.grad] + [PA[k].grad for k in sorted(PA)] + \
                         [PB[k].grad for k in sorted(PB)]
+        # bit-identical when the pair runs the same kernel instantiation as the single sweeps; in the 256-workgroup mode
+        # a pair of 128-row sweeps at H = 512 runs 32 rows per workgroup (the 1-D backward kernel) while the single sweeps
+        # run 16 (the 2-D backward kernel): same arithmetic, another fp32 summation order over the hidden units
+        pg = ops.lstm_pair_geometry(B0, B1, H)
+        same_kernel = pg is None or (pg[0] == ops.lstm_geometry(B0, H)[0] == ops.lstm_geometry(B1, H)[0])
         for a, b in zip(res['seq'], res['pair']):
             if a.dim() == 1:        # bias gradients: a4nt_colsum adds its row chunks with atomics (order varies run to run)
                 assert_close(b, a, 2e-6, 'bias gradient')
-            else:
+            elif same_kernel:
                 assert torch.equal(a, b)
+            else:
+                assert_close(b, a, 5e-6, 'pair vs sequential, different row tiling')
     finally:
         ops.PAIR_LSTM = True
         ops.lstm_set_max_workgroups(512)

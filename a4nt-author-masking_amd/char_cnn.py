@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import ops
+from .model_utils import ids_to_device
 from .gen_decode import SoftSamples, sample_embed
 
 
@@ -281,7 +282,7 @@ class CharCNN(nn.Module):
             elif adv_inp:
                 emb = ops.linear_kn(x.reshape(T * B, -1), self.encoder.weight).view(T, B, -1)
             else:
-                emb = ops.embedding(x.to(dev), self.encoder.weight, 0)
+                emb = ops.embedding(ids_to_device(x, dev), self.encoder.weight, 0)
             cur = self._drop(emb, self.p_enc)                      # [T,B,C] time major throughout
             inputs = [cur]
             drop_active = self.training and self.p_dec > 0.0

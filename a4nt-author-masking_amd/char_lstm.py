@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .gen_decode import SoftSamples, sample_embed
-from .model_utils import (build_rec, fill_forget_bias, lens_to_device, run_stack, run_stack_bidir, packed_mean,
+from .model_utils import (ids_to_device, build_rec, fill_forget_bias, lens_to_device, run_stack, run_stack_bidir, packed_mean,
                           check_hidden)
 
 
@@ -118,7 +118,7 @@ class CharLstm(nn.Module):
         self._need_generative('forward')
         dev = self.decoder_W.device
         T, B = x.shape
-        emb = self._drop(ops.embedding(x.to(dev), self.encoder.weight, 0), self.p_enc, True)
+        emb = self._drop(ops.embedding(ids_to_device(x, dev), self.encoder.weight, 0), self.p_enc, True)
         rnn_out, hidden = self._rec(emb, lengths, h_prev)
         n_t = max(int(l) for l in lengths)
         rnn_out = self._drop(rnn_out[:n_t], self.p_dec, True)
@@ -141,7 +141,7 @@ class CharLstm(nn.Module):
         self._need_generative('forward_eval')
         dev = self.decoder_W.device
         with torch.no_grad():
-            emb = ops.embedding(x.to(dev), self.encoder.weight, 0)
+            emb = ops.embedding(ids_to_device(x, dev), self.encoder.weight, 0)
             rnn_out, hidden = self._rec(emb, None, h_prev)
             h2 = rnn_out.reshape(-1, self.hidden_size)
             out = torch.stack([ops.linear_kn(h2, self.decoder_W[c], self.decoder_b[c])
@@ -159,7 +159,7 @@ class CharLstm(nn.Module):
         c = int(target_auth.view(-1)[0])
         char_out = []
         with torch.no_grad():
-            emb = ops.embedding(x.to(dev), self.encoder.weight, 0)
+            emb = ops.embedding(ids_to_device(x, dev), self.encoder.weight, 0)
             rnn_out, hidden = self._rec(emb, None, h_prev)
             p_rnn = rnn_out[-1]
             for _ in range(n_max):
@@ -183,7 +183,7 @@ class CharLstm(nn.Module):
             elif adv_inp:
                 comp = ops.linear_kn(x.reshape(T * B, -1), self.compression_W.weight)
             else:
-                comp = ops.embedding(x.to(dev), self.compression_W.weight, -1).view(T * B, -1)
+                comp = ops.embedding(ids_to_device(x, dev), self.compression_W.weight, -1).view(T * B, -1)
             qn = comp.abs().sum(dim=1, keepdim=True)
             if adv_inp or isinstance(x, SoftSamples):
                 qn = qn.detach()
@@ -193,7 +193,7 @@ class CharLstm(nn.Module):
         elif adv_inp:
             emb = ops.linear_kn(x.reshape(T * B, -1), self.encoder.weight).view(T, B, -1)
         else:
-            emb = ops.embedding(x.to(dev), self.encoder.weight, 0)
+            emb = ops.embedding(ids_to_device(x, dev), self.encoder.weight, 0)
         return self._drop(emb, self.p_enc, drop)
 
     def _classify_emb(self, emb, lens, h_prev, compute_softmax, drop):

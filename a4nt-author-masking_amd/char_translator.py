@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .gen_decode import SoftSamples, sample_embed, gen_decode
-from .model_utils import (build_rec, rec_layer_params, fill_forget_bias, lens_to_device, run_stack, packed_mean,
+from .model_utils import (ids_to_device, build_rec, rec_layer_params, fill_forget_bias, lens_to_device, run_stack, packed_mean,
                           check_hidden)
 
 class CharTranslator(nn.Module):
@@ -142,7 +142,7 @@ class CharTranslator(nn.Module):
         if adv_inp:
             T, B = x.shape[0], x.shape[1]
             return ops.linear_kn(x.reshape(T * B, -1), self.char_emb.weight).view(T, B, -1)
-        emb = ops.embedding(x.to(self._dev()), self.char_emb.weight, 0)
+        emb = ops.embedding(ids_to_device(x, self._dev()), self.char_emb.weight, 0)
         return self._drop(emb, self.p_emb) if drop else emb
 
     def _encode(self, emb, lengths, h_prev):
@@ -188,7 +188,7 @@ class CharTranslator(nn.Module):
                     targ.shape[0], targ.shape[1], -1)
             targ_emb = self._drop(t_emb, self.p_emb)
         else:
-            targ = targ.to(dev)
+            targ = ids_to_device(targ, dev)
             targ_emb = self._drop(ops.embedding(targ, self.char_emb.weight, 0), self.p_emb)
         n_t = targ.shape[0]
         lens_dev = lens_to_device(lengths_targ, n_t, dev)
@@ -294,7 +294,7 @@ class CharTranslator(nn.Module):
         cfg = dict(n_max=n_max, end_c=int(end_c), tau=float(temp), scale=float(self.softmax_scale),
                    hard=bool(self.gumb_type), greedy=not soft_samples, need_grad=need_grad, noise=self._noise,
                    seed=self.noise_seed, step0=self._noise_step, grad_rows=grad_rows)
-        tok0 = x.tok[0] if isinstance(x, SoftSamples) else x[0].to(dev)
+        tok0 = x.tok[0] if isinstance(x, SoftSamples) else ids_to_device(x[0], dev)
         samples, gen_lens, tok = gen_decode(ctxt, tok0, self.char_emb.weight, w_ih, w_hh, b_ih, b_hh,
                                             W_out, dec[2], cfg)
         self._noise_step += n_max
@@ -319,7 +319,7 @@ class CharTranslator(nn.Module):
         elif soft_in:
             targ_emb = ops.linear_kn(x[0], self.char_emb.weight)
         else:
-            targ_emb = ops.embedding(x[0].to(dev), self.char_emb.weight, 0)
+            targ_emb = ops.embedding(ids_to_device(x[0], dev), self.char_emb.weight, 0)
         dec_bsz = B * n_samples
         ctxt_rep = ctxt.repeat(n_samples, 1)
         dec_inp = torch.cat([ctxt, targ_emb], dim=-1).repeat(n_samples, 1)

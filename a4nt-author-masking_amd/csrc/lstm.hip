@@ -289,6 +289,10 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bi
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NJ>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) { lstm_fwd_body<MT, NJ>(a, blockIdx.x); }
+// the single free-running decoder step (mode = 1) under a name of its own, so that profiles tell the 100 short steps
+// of a generation from the full sweeps
+template <int MT, int NJ>
+__global__ __launch_bounds__(256) void lstm_dec_kernel(LstmFwdArgs a) { lstm_fwd_body<MT, NJ>(a, blockIdx.x); }
 
 // Two independent sweeps in one launch (a4nt_lstm_seq_fwd_pair): workgroups [0, nA) run problem a, the rest
 // problem b, each with its own exchange buffer and counters.  Neither sweep fills the chip alone (128 rows
@@ -1069,7 +1073,7 @@ extern "C" int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const
     a.mode = 1; a.step0 = step;
     dim3 grid(G * a.NW), block(256);
     hipStream_t s = (hipStream_t)stream;
-    A4NT_DISPATCH_LSTM(lstm_fwd_kernel, mt, H / 64, grid, block, s, a);
+    A4NT_DISPATCH_LSTM(lstm_dec_kernel, mt, H / 64, grid, block, s, a);
     return a4nt_check_launch("lstm_dec_step");
 }
 

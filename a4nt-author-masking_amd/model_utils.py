@@ -97,6 +97,14 @@ def run_stack_bidir(rec, x, lens, depth, h_prev=None):
     return cur, (torch.stack(hs, 0), torch.stack(cs, 0))
 
 
+def ids_to_device(x, device):
+    """Token ids (CPU int64, as the callers hand them over: char_translator.py:208, char_lstm.py:273) -> device.
+    non_blocking: from the pinned staging tensors of data_provider.prepare_data this is an asynchronous DMA the host
+    does not wait for (torch's pinned-memory allocator keeps the block until the copy's event has passed); from
+    pageable memory torch stages the copy itself."""
+    return x if x.device == device else x.to(device, non_blocking=True)
+
+
 def lens_to_device(lens, T, device):
     """Length list (sorted or not) -> int32 device vector, or None when every row runs T steps."""
     if lens is None:

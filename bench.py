@@ -78,7 +78,8 @@ def make_batches(impl, seed, batch, n, ragged=False):
     out = []
     for _ in range(n):
         b = impl.synthetic_batch(g, T, batch, V, lens=ragged_lens(g, batch) if ragged else None)
-        out.append(b)
+        # pinned, as DataProvider.prepare_data stages them: the modules' id copies are then asynchronous DMAs
+        out.append((b[0].pin_memory(), b[1].pin_memory(), b[2]))
     return out
 
 
@@ -150,17 +151,43 @@ def cpu_baseline(batch_cpu=B):
                       'V=%d, oracle/ on torch CPU fp32, %.1f s' % (batch_cpu, B, T, V + 1, dt)}
 
 
+def _latest_profile(stem):
+    """profiles/rNN_<stem>.json of the latest round that has one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s.json' % stem)))
+    return files[-1] if files else None
+
+
 def pmc_traffic(label):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and
+    (profiles/rNN_pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and
     WRITE_SIZE runs of this same command); None when that kernel has no entry."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    if not os.path.exists(path):
+    path = _latest_profile('pmc_traffic')
+    if path is None:
         return None
     with open(path) as f:
         tab = json.load(f)
     ent = tab.get('kernels', {}).get(label)
     return ent['hbm_bytes_per_launch'] if ent else None
+
+
+def lstm_mfma_util():
+    """BASELINE.json's second metric: matrix-pipe utilisation of the LSTM kernels (MFMA-busy cycles / (active cycles
+    x 1024 SIMDs)) from the committed counter pass over this same command (profiles/rNN_pmc_mfma.json,
+    tools/pmc_mfma.py).  Counters cannot be read from inside the timed run, so these are the committed profile's
+    numbers, named with their source; None when no profile is committed."""
+    path = _latest_profile('pmc_mfma')
+    if path is None:
+        return None
+    with open(path) as f:
+        tab = json.load(f)
+    out = {'source': os.path.relpath(path, ROOT)}
+    for key, lab in (('fwd_sweep', 'lstm_fwd'), ('fwd_sweep_pair', 'lstm_fwd_pair'), ('bwd_sweep', 'lstm_bwd'),
+                     ('bwd_sweep_pair', 'lstm_bwd_pair'), ('decoder_step', 'lstm_dec_step'),
+                     ('fwd_sweeps_and_decoder_steps', 'lstm_fwd (sweeps and decoder steps)')):
+        if lab in tab:
+            out[key] = round(tab[lab]['mfma_util'], 4)
+    return out
 
 
 def _synth(g, batch):
@@ -177,8 +204,8 @@ def _synth(g, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='adv', choices=sorted(WORKLOADS), help='default: the metric\'s configuration')
     ap.add_argument('--ragged', action='store_true', help='speech-shaped sentence lengths instead of all = T')
     ap.add_argument('--batch', type=int, default=None, help='sentences per GPU (default: the workload\'s)')
@@ -311,6 +338,9 @@ def main():
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'losses_finite': loss_ok},
             'roofline': dict({'bound': 'mfma', 'traffic': pmc_traffic(timer['name'])}, **main_rl),
         }
+        util = lstm_mfma_util()
+        if util is not None and args.workload in ('adv', 'cfg5'):
+            line['lstm_mfma_util'] = util
         if others:
             line['roofline']['other_kernels'] = others
         if world == 1 and not args.no_cpu_baseline and args.workload == 'adv' and not args.ragged:

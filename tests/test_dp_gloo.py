@@ -94,3 +94,96 @@ def test_single_process_is_noop():
     red.launch()
     red.wait()
     assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+# ----------------------------------------------------------------------------------------------
+# two models, two reducers in flight one after the other, ragged per-token loss (token_weight) and the scalar
+# all-reduce -- the reducer usage pattern of adv_step.fused_update (discriminator step, then generator step with a
+# per-token reconstruction CE), with CPU oracle models standing in for the HIP modules
+GP2 = dict(vocabulary_size=40, embedding_size=12, enc_hidden_size=16, dec_hidden_size=16, enc_hidden_depth=1,
+           dec_hidden_depth=1, en_residual_conn=0, pad_auth_vec=4, num_output_layers=2, batch_size=8,
+           drop_prob_emb=0.0, drop_prob_encoder=0.0, drop_prob_decoder=0.0)
+LENS2 = [6, 6, 5, 5, 4, 3, 2, 2]          # sorted; rank 0 holds 22 of the 33 tokens
+
+
+def _data2():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(1, 41, (T, B), generator=g)
+    y = torch.randint(1, 41, (T, B), generator=g)
+    for b, l in enumerate(LENS2):
+        x[l:, b] = 0
+        y[l:, b] = 0
+    lab = torch.randint(0, 2, (B,), generator=g)
+    return x, y, lab
+
+
+def _two_model_step(oracle, G, D, x, y, lab, lens, redG, redD, n_glob_rows):
+    """D-like step (mean over sentences) then G-like step (mean over valid tokens, token-weighted)."""
+    from torch.nn.utils.rnn import pack_padded_sequence as pps
+    D.zero_grad(); G.zero_grad()
+    logits, _ = D.forward_classify(x, lens=lens)
+    if redD is not None:
+        redD.arm()
+    F.cross_entropy(logits, lab).backward()
+    if redD is not None:
+        redD.launch()                                        # in flight while the generator-side forward runs
+    scores, _ = G.forward_mltrain(x, lens, x, lens, auths=torch.zeros(len(lens), dtype=torch.long))
+    ce = F.cross_entropy(pps(scores, lens)[0], pps(y, lens)[0])
+    w = redG.token_weight(sum(lens)) if redG is not None else 1.0
+    if redD is not None:
+        redD.wait()
+    if redG is not None:
+        redG.arm()
+    (ce * w).backward()
+    if redG is not None:
+        redG.launch()
+        redG.wait()
+
+
+def _worker2(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oracle
+    from a4nt_amd import GradAllReducer
+    torch.manual_seed(0)
+    G, D = oracle.CharTranslator(GP2), oracle.CharLstm(EP)
+    x, y, lab = _data2()
+    b = B // world
+    sh = slice(rank * b, (rank + 1) * b)
+    lens = LENS2[sh]
+    redG = GradAllReducer(list(G.parameters()), bucket_mb=0.001)
+    redD = GradAllReducer(list(D.parameters()), bucket_mb=0.001)
+    for it in range(3):                      # step 0 learns the bucket order of BOTH reducers, 1-2 overlap
+        _two_model_step(oracle, G, D, x[:max(lens), sh], y[:max(lens), sh], lab[sh], lens, redG, redD, B)
+    cnt = redD.all_reduce_scalars(torch.tensor([float(sum(lens)), 1.0]))
+    if rank == 0:
+        out_q.put(({n: p.grad.numpy().copy() for n, p in G.named_parameters()},
+                   {n: p.grad.numpy().copy() for n, p in D.named_parameters()}, cnt.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_reducers_ragged_tokens_equal_one_big_batch():
+    import oracle
+    torch.manual_seed(0)
+    G, D = oracle.CharTranslator(GP2), oracle.CharLstm(EP)
+    x, y, lab = _data2()
+    _two_model_step(oracle, G, D, x, y, lab, LENS2, None, None, B)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker2, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gG, gD, cnt = q.get(timeout=150)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert cnt == [float(sum(LENS2)), 2.0]
+    for n, p in D.named_parameters():
+        assert torch.allclose(torch.from_numpy(gD[n]), p.grad, rtol=1e-5, atol=1e-7), 'D ' + n
+    for n, p in G.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.allclose(torch.from_numpy(gG[n]), g, rtol=2e-5, atol=1e-7), 'G ' + n

@@ -21,12 +21,15 @@ import sys
 from collections import defaultdict
 
 LABELS = [
-    (r'sgemm_kernel<(true|false), (true|false), (\d), \d, \d(?:, \d)?>', None),
+    (r'sgemm_kernel<(true|false), (true|false), (\d), \d, \d(?:, \d)?(?:, (?:true|false))?>', None),
     (r'lstm_fwd2_kernel', 'lstm_seq_fwd_pair'),
-    (r'lstm_bwd2_kernel', 'lstm_seq_bwd_pair'),
+    (r'lstm_bwd2d2_kernel|lstm_bwd2_kernel', 'lstm_seq_bwd_pair'),
     (r'nt_rows_kernel', 'sgemm_nt_rows'),
-    (r'lstm_fwd_kernel', 'lstm_fwd_kernel'),
-    (r'lstm_bwd_kernel', 'lstm_seq_bwd'),
+    (r'lstm_dec_kernel', 'lstm_dec_step'),
+    (r'lstm_fwd_kernel', 'lstm_seq_fwd'),
+    (r'lstm_bwd2d_kernel|lstm_bwd_kernel', 'lstm_seq_bwd'),
+    (r'nll_grad_rows_kernel', 'nll_grad_rows'),
+    (r'conv1d_kernel', 'conv1d'),
     (r'proj_gumbel_kernel', 'proj_gumbel'),
     (r'proj_gumbel_final_kernel', 'proj_gumbel_final'),
     (r'gumbel_bwd_kernel', 'gumbel_bwd'),
@@ -40,7 +43,8 @@ def label_of(name):
     m = re.search(LABELS[0][0], name)
     if m:
         ta, tb, w = m.group(1) == 'true', m.group(2) == 'true', int(m.group(3))
-        return 'sgemm_%s_%d' % ('tn' if ta else ('nt' if tb else 'nn'), 128 if w == 2 else 64)
+        nll = '_nll' if re.search(r', true>', name[m.start():m.end()]) and not ta and not tb and name[m.start():m.end()].count(',') >= 6 else ''
+        return 'sgemm_%s_%d%s' % ('tn' if ta else ('nt' if tb else 'nn'), 128 if w == 2 else 64, nll)
     for pat, lab in LABELS[1:]:
         if re.search(pat, name):
             return lab
@@ -61,8 +65,6 @@ def collect(d, counter):
                 lab = label_of(row['Kernel_Name'])
                 if lab is None:
                     continue
-                # the sequence sweeps and the single decoder steps share lstm_fwd_kernel: tell them apart by
-                # nothing the counter file holds, so keep them as one entry
                 acc[lab][0] += float(row['Counter_Value'])
                 acc[lab][1] += 1
     return acc

@@ -102,11 +102,42 @@ __global__ void slab_reduce_kernel(int S, long long stride, int R, int C, const 
         out[(long long)r * ldo + c] = v;
     }
 }
+// the same with 16-byte accesses (every row start and leading dimension 16-byte aligned, C a multiple of 4): the
+// per-step reductions of the decoder's reverse loop are latency bound -- S independent 16-byte loads per thread
+// in flight instead of S dependent-looking 4-byte ones
+template <int SMAX>
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(int S, long long stride, int R, int C4, const float* slabs,
+                                                           int lds, int c0, const float* add, int lda, float* out, int ldo) {
+    const int total = R * C4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / C4, c = 4 * (i - r * C4);
+        const float* p = slabs + (long long)r * lds + c0 + c;
+        f32x4 v[SMAX];
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s)
+            if (s < S) v[s] = *reinterpret_cast<const f32x4*>(p + s * stride);
+        f32x4 acc = add ? *reinterpret_cast<const f32x4*>(add + (long long)r * lda + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s)
+            if (s < S) { acc.x += v[s].x; acc.y += v[s].y; acc.z += v[s].z; acc.w += v[s].w; }
+        *reinterpret_cast<f32x4*>(out + (long long)r * ldo + c) = acc;
+    }
+}
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 extern "C" int a4nt_slab_reduce(int S, long long stride, int R, int C, const float* slabs, int lds, int c0,
                                 const float* add, int lda, float* out, int ldo, void* stream) {
     if (R <= 0 || C <= 0) return A4NT_OK;
     if (S < 1 || !slabs || !out) { a4nt_set_error("a4nt_slab_reduce: bad arguments"); return A4NT_ERR_ARG; }
     const long long total = (long long)R * C;
+    if (S <= 16 && (C & 3) == 0 && (lds & 3) == 0 && (c0 & 3) == 0 && (ldo & 3) == 0 && (stride & 3) == 0 && al16(slabs) &&
+        al16(out) && (!add || ((lda & 3) == 0 && al16(add))) && total / 4 < 0x7fffffffll) {
+        const int n4 = (int)(total / 4);
+        const int bs = n4 <= 65536 ? 64 : 256;          // small (per-step) reductions: one wave per workgroup, on every CU
+        const int grid = min(2048, (n4 + bs - 1) / bs);
+        if (S <= 8) hipLaunchKernelGGL((slab_reduce4_kernel<8>), dim3(grid), dim3(bs), 0, (hipStream_t)stream, S, stride, R, C / 4, slabs, lds, c0, add, lda, out, ldo);
+        else hipLaunchKernelGGL((slab_reduce4_kernel<16>), dim3(grid), dim3(bs), 0, (hipStream_t)stream, S, stride, R, C / 4, slabs, lds, c0, add, lda, out, ldo);
+        return a4nt_check_launch("slab_reduce");
+    }
     const int grid = (int)min((long long)1024, (total + 255) / 256);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, S, stride, R, C, slabs, lds, c0,
                        add, lda, out, ldo);
@@ -137,12 +168,64 @@ __global__ void lstm_cell_bwd_kernel(int B, int H, const float* gates, const flo
         dc_io[i] = dc * fg;
     }
 }
+// four units per thread through 16-byte accesses, all loads of a thread issued before the first use (same
+// arithmetic per element, same order of the slab sum)
+template <int SMAX>
+__global__ __launch_bounds__(256) void lstm_cell_bwd4_kernel(int B, int H, const float* gates, const float* c_t,
+                                                             const float* c_prev, const float* dh_slabs, int n_slabs,
+                                                             long long slab_stride, const float* dh_b, int ldb,
+                                                             float* dc_io, float* dgates) {
+    const int H4q = H >> 2, total = B * H4q;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / H4q, u = 4 * (i - b * H4q);
+        const long long e = (long long)b * H + u;
+        const float* pg = gates + (long long)b * 4 * H + u;
+        const f32x4 ig = *reinterpret_cast<const f32x4*>(pg), fg = *reinterpret_cast<const f32x4*>(pg + H);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(pg + 2 * H), og = *reinterpret_cast<const f32x4*>(pg + 3 * H);
+        const f32x4 ct = *reinterpret_cast<const f32x4*>(c_t + e);
+        const f32x4 cp = c_prev ? *reinterpret_cast<const f32x4*>(c_prev + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 dci = *reinterpret_cast<const f32x4*>(dc_io + e);
+        f32x4 sl[SMAX];
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s)
+            if (s < n_slabs) sl[s] = *reinterpret_cast<const f32x4*>(dh_slabs + s * slab_stride + e);
+        f32x4 dh = dh_b ? *reinterpret_cast<const f32x4*>(dh_b + (long long)b * ldb + u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s)
+            if (s < n_slabs) { dh.x += sl[s].x; dh.y += sl[s].y; dh.z += sl[s].z; dh.w += sl[s].w; }
+        f32x4 di, df, dg, dO, dcn;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float tc = tanhf_(ct[k]);
+            const float dc = dci[k] + dh[k] * og[k] * (1.f - tc * tc);
+            di[k] = dc * gg[k] * ig[k] * (1.f - ig[k]);
+            df[k] = dc * cp[k] * fg[k] * (1.f - fg[k]);
+            dg[k] = dc * ig[k] * (1.f - gg[k] * gg[k]);
+            dO[k] = dh[k] * tc * og[k] * (1.f - og[k]);
+            dcn[k] = dc * fg[k];
+        }
+        float* pd = dgates + (long long)b * 4 * H + u;
+        *reinterpret_cast<f32x4*>(pd) = di; *reinterpret_cast<f32x4*>(pd + H) = df;
+        *reinterpret_cast<f32x4*>(pd + 2 * H) = dg; *reinterpret_cast<f32x4*>(pd + 3 * H) = dO;
+        *reinterpret_cast<f32x4*>(dc_io + e) = dcn;
+    }
+}
 extern "C" int a4nt_lstm_cell_bwd(int B, int H, const float* gates, const float* c_t, const float* c_prev,
                                   const float* dh_slabs, int n_slabs, long long slab_stride, const float* dh_b, int ldb,
                                   float* dc_io, float* dgates, void* stream) {
     if (B <= 0 || H <= 0) return A4NT_OK;
     if (!gates || !c_t || !dc_io || !dgates || (n_slabs > 0 && !dh_slabs)) { a4nt_set_error("a4nt_lstm_cell_bwd: bad arguments"); return A4NT_ERR_ARG; }
     const long long total = (long long)B * H;
+    if ((H & 3) == 0 && n_slabs <= 16 && (slab_stride & 3) == 0 && al16(gates) && al16(c_t) && (!c_prev || al16(c_prev)) &&
+        (n_slabs == 0 || al16(dh_slabs)) && (!dh_b || ((ldb & 3) == 0 && al16(dh_b))) && al16(dc_io) && al16(dgates) &&
+        total / 4 < 0x7fffffffll) {
+        const int n4 = (int)(total / 4);
+        const int bs = n4 <= 65536 ? 64 : 256;
+        const int grid = min(2048, (n4 + bs - 1) / bs);
+        if (n_slabs <= 4) hipLaunchKernelGGL((lstm_cell_bwd4_kernel<4>), dim3(grid), dim3(bs), 0, (hipStream_t)stream, B, H, gates, c_t, c_prev, dh_slabs, n_slabs, slab_stride, dh_b, ldb, dc_io, dgates);
+        else hipLaunchKernelGGL((lstm_cell_bwd4_kernel<16>), dim3(grid), dim3(bs), 0, (hipStream_t)stream, B, H, gates, c_t, c_prev, dh_slabs, n_slabs, slab_stride, dh_b, ldb, dc_io, dgates);
+        return a4nt_check_launch("lstm_cell_bwd");
+    }
     const int grid = (int)min((long long)1024, (total + 255) / 256);
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, H, gates, c_t, c_prev,
                        dh_slabs, n_slabs, slab_stride, dh_b, ldb, dc_io, dgates);

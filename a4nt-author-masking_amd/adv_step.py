@@ -43,7 +43,7 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
         before_disc()                   # e.g. the deferred discriminator step: the generation above did not need it
     if grad_filter:
         samples.set_grad_filter()
-    gl_host = gen_lens.cpu()
+    gl_host = ops.host_lens(gen_lens)
     assert int(gl_host.min()) > 0
     len_sorted, sort_idx = gl_host.sort(dim=0, descending=True, stable=True)
     _, rev_sort_idx = sort_idx.sort(dim=0)
@@ -531,11 +531,13 @@ def fused_update(modelGen, modelEval, optimGen, optimEval, src_batch, tgt_batch,
     samples, gen_lens, char_outs = modelGen.forward_advers_gen(
         torch.cat([s_inps, g_inps], dim=1), list(s_lens) + list(g_lens), soft_samples=True, end_c=end_c, n_max=maxlen,
         temp=temp, auths=1 - torch.cat([s_auths, g_auths]), compact=True, grad_rows=(B, 2 * B))
-    gl = gen_lens.cpu()
+    gl = ops.host_lens(gen_lens)
     n_d, n_g = int(gl[:B].max()), int(gl[B:].max())
     tok = torch.stack(list(char_outs), 0) if not torch.is_tensor(char_outs) else char_outs
-    gen_d = (samples.rows(0, B, n_d, differentiable=False), gen_lens[:B], list(tok[:n_d, :B].unbind(0)))
-    gen_g = (samples.rows(B, 2 * B, n_g), gen_lens[B:], list(tok[:n_g, B:].unbind(0)))
+    lens_d = ops.attach_host_lens(gen_lens[:B], gl[:B])
+    lens_g = ops.attach_host_lens(gen_lens[B:], gl[B:])
+    gen_d = (samples.rows(0, B, n_d, differentiable=False), lens_d, list(tok[:n_d, :B].unbind(0)))
+    gen_g = (samples.rows(B, 2 * B, n_g), lens_g, list(tok[:n_g, B:].unbind(0)))
     rd = d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c, maxlen, temp, step=step,
                   reducer=reducers[1], gen=gen_d)
     rg = g_update(modelGen, modelEval, optimGen, gen_batch, c_aid, end_c, maxlen, temp, append_symb,

@@ -284,7 +284,11 @@ class _GenDecode(Function):
                 ev = torch.cuda.Event()
                 ev.record()
                 pending = (ev, flag)
-        n_out = int(gen_lens.max().item())          # = steps the reference loop would have run
+        # the one read-back of a generation: every later consumer of the lengths (the length sort, the row split of
+        # fused_update) takes this host copy (ops.host_lens) instead of draining the GPU again
+        gl_host = gen_lens.cpu()
+        holder['lens_host'] = gl_host
+        n_out = int(gl_host.max())                  # = steps the reference loop would have run
         n_out = max(1, min(n_out, ran))
         if noise is not None and not greedy:
             # the reference stops drawing noise when its loop breaks: consume exactly n_out draws
@@ -302,7 +306,7 @@ class _GenDecode(Function):
                                       val_out)
             else:
                 # keep only the rows that will be differentiated, as dense [.., r1-r0, ..] tensors
-                ctx.n = n_g = max(1, min(int(gen_lens[r0:r1].max().item()), ran))
+                ctx.n = n_g = max(1, min(int(gl_host[r0:r1].max()), ran))
                 sl = lambda t_: t_[:, r0:r1].contiguous()
                 ctx.save_for_backward(ctxt[r0:r1].contiguous(), tok0[r0:r1].contiguous(), emb_W, w_ih, w_hh_c, W_out,
                                       sl(hs_all[:n_g + 1]), sl(gates[:n_g]), sl(cs[:n_g]), ybuf, sl(stats[:n_g]),
@@ -428,4 +432,5 @@ def gen_decode(ctxt, tok0, emb_W, w_ih, w_hh, b_ih, b_hh, W_out, b_out, cfg):
     if not cfg['greedy']:
         origin = (holder['handle'], 0, None) if holder['handle'] is not None else None
         samples = SoftSamples(tok, val_out, emb_W.shape[0], origin)
+    ops.attach_host_lens(gen_lens, holder['lens_host'])
     return samples, gen_lens, tok

@@ -547,6 +547,19 @@ class _LstmLayer(Function):
 HIDDEN_SIZES = (64, 128, 256, 512, 1024)      # instantiations of the persistent sweeps (lstm.hip)
 
 
+def attach_host_lens(lens_dev, lens_host):
+    """Remember the host copy of a device length vector that has already been read back (one read-back per
+    generation, gen_decode._GenDecode.forward); host_lens() hands it to later consumers."""
+    lens_dev._a4nt_host = lens_host
+    return lens_dev
+
+
+def host_lens(lens_dev):
+    """Host copy of a length vector: the attached one when the producer read it back already, else a D2H copy."""
+    h = getattr(lens_dev, '_a4nt_host', None)
+    return h if h is not None else lens_dev.cpu()
+
+
 def padded_hidden(H):
     """The kernel hidden size that serves a model hidden size H: the next instantiated size."""
     for hp in HIDDEN_SIZES:

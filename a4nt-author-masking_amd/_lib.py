@@ -72,6 +72,8 @@ _SIGS = {
     'a4nt_lstm_seq_bwd_pair': (c_int, [c_int, POINTER(LstmBwdProblem), POINTER(LstmBwdProblem), P]),
     'a4nt_lstm_check_timeout': (c_int, [P, c_int, P]),
     'a4nt_lstm_dec_step': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
+    'a4nt_lstm_dec_step_merge': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int, P, c_float, c_int, c_int, P, P,
+                                         P, P, P, P, c_longlong, P]),
     'a4nt_gen_loop_fwd': (c_int, [POINTER(GenFwdArgs), c_int, c_int, P]),
     'a4nt_gen_loop_bwd': (c_int, [POINTER(GenBwdArgs), P]),
     'a4nt_lstm_cell_bwd': (c_int, [c_int, c_int, P, P, P, P, c_int, c_longlong, P, c_int, P, P, P]),
@@ -83,13 +85,15 @@ _SIGS = {
     'a4nt_proj_gumbel_part_floats': (c_longlong, [c_int, c_int]),
     'a4nt_proj_gumbel_fwd': (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_float, c_float, c_int, c_int, P, c_int,
                                      c_ulonglong, c_uint, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_longlong, P]),
+    'a4nt_proj_gumbel_finalize': (c_int, [c_int, c_int, P, c_float, c_int, c_int, P, P, P, P, P, P, c_longlong, P]),
     'a4nt_nll_rows': (c_int, [c_int, c_int, P, c_int, P, c_float, P, c_int, P]),
     'a4nt_sgemm_nll_parts': (c_int, [c_int]),
     'a4nt_sgemm_nll': (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
     'a4nt_nll_grad_rows': (c_int, [c_int, c_int, P, c_int, P, P, c_int, c_float, P, c_int, P]),
     'a4nt_embed_fwd': (c_int, [c_longlong, c_int, c_int, P, P, P, P, c_int, P]),
     'a4nt_embed_bwd': (c_int, [c_longlong, c_int, c_int, P, P, P, c_int, P, c_longlong, P]),
-    'a4nt_colsum': (c_int, [c_int, c_int, P, c_int, P, c_int, P]),
+    'a4nt_colsum_ws_floats': (c_longlong, [c_int, c_int]),
+    'a4nt_colsum': (c_int, [c_int, c_int, P, c_int, P, c_int, P, c_longlong, P]),
     'a4nt_slab_reduce': (c_int, [c_int, c_longlong, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, P]),
     'a4nt_conv1d_tm': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_float, P, c_int, c_int,
                                c_int, c_int, c_int, P, P]),

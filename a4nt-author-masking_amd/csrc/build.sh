@@ -1,8 +1,10 @@
 #!/bin/bash
-# Builds liba4nt_hip.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh [-j N]
+# Builds liba4nt_hip.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh [--clean]
+# --clean: compile every source again instead of reusing objects newer than their sources.
 set -e
 cd "$(dirname "$0")"
 ARCH=gfx950
+if [ "$1" = "--clean" ]; then rm -f ./*.o ../liba4nt_hip.so; fi
 FLAGS="-O3 -std=c++17 --offload-arch=$ARCH -fPIC -fno-gpu-rdc -Wno-unused-result"
 OBJS=""
 pids=()

@@ -24,6 +24,14 @@ void a4nt_set_error(const char* fmt, ...);
 int a4nt_check_launch(const char* what);
 int a4nt_lstm_probe_occupancy(int device, int num_cus);     // lstm.hip, called by a4nt_init
 
+// The sampler's finalisation (projgumbel.hip): merge the per-strip (max, sum exp, argmax) partials of a row, then the
+// bookkeeping of one decoding step.  Run by proj_gumbel_final_kernel, or by the next decoder step's prologue (lstm.hip).
+#define PG_BC 80          // strip width of the fused projection: five 16-column MFMA tiles per wave
+struct PgFinalArgs {
+    const float* part; int nstrips; float inv_tau; int greedy; int hard;
+    float* stats; long long* tok; float* val_in; float* val_out; int* gen_lens; unsigned char* done; long long end_c;
+};
+
 // ---------------------------------------------------------------------------------------------
 // inter-workgroup hand-off primitives (persistent LSTM kernels)
 //

@@ -28,19 +28,31 @@ extern "C" int a4nt_gen_loop_fwd(const a4nt_gen_fwd_args* a, int t0, int t1, voi
     }
     const long long B = a->B, H = a->H;
     for (int t = t0; t < t1; ++t) {
-        const long long* tk = t == 0 ? a->tok0 : a->tok + (t - 1) * B;
-        const float* vl = t == 0 ? a->ones : a->val_in + (t - 1) * B;
         const float* cp = t == 0 ? nullptr : a->cs + (t - 1) * B * H;
         float* h_t = a->hs_all + (long long)(t + 1) * B * H;
-        int rc = a4nt_lstm_dec_step(t, a->B, a->H, a->cg, a->ptab, tk, vl, a->whh, cp, h_t, a->gates + t * B * 4 * H,
+        int rc;
+        if (t == t0) {
+            // the step before this chunk (or the start token) is final in memory
+            const long long* tk = t == 0 ? a->tok0 : a->tok + (t - 1) * B;
+            const float* vl = t == 0 ? a->ones : a->val_in + (t - 1) * B;
+            rc = a4nt_lstm_dec_step(t, a->B, a->H, a->cg, a->ptab, tk, vl, a->whh, cp, h_t, a->gates + t * B * 4 * H,
                                     a->cs + t * B * H, a->xch, stream);
+        } else {
+            // the sampler of step t-1 is finished in this step's prologue (no launch of its own)
+            rc = a4nt_lstm_dec_step_merge(t, a->B, a->H, a->cg, a->ptab, a->whh, cp, h_t, a->gates + t * B * 4 * H,
+                                          a->cs + t * B * H, a->xch, a->V, a->part, a->tau, a->hard, a->greedy,
+                                          a->stats + (t - 1) * B * 2, a->tok + (t - 1) * B, a->val_in + (t - 1) * B,
+                                          a->val_out + (t - 1) * B, a->gen_lens, a->done, a->end_c, stream);
+        }
         if (rc != A4NT_OK) return rc;
         const float* U = (a->U && t < a->n_noise) ? a->U[t] : nullptr;
         float* z = a->z ? a->z + (long long)t * a->zrows * a->ldz : nullptr;
+        const bool last = t == t1 - 1;                 // the chunk's last step is finalised by a launch of its own
         rc = a4nt_proj_gumbel_fwd(a->B, a->V, a->H, h_t, a->H, a->W, a->ldw, a->bias, a->scale, a->tau, a->hard, a->greedy, U,
                                   U ? a->ldu : 0, a->seed, a->step0 + (unsigned)t, z, z ? a->ldz : 0, a->zrow0,
-                                  z ? a->zrows : 0, a->part, a->stats + t * B * 2, a->tok + t * B, a->val_in + t * B,
-                                  a->val_out + t * B, a->gen_lens, a->done, a->end_c, stream);
+                                  z ? a->zrows : 0, a->part, last ? a->stats + t * B * 2 : nullptr, last ? a->tok + t * B : nullptr,
+                                  last ? a->val_in + t * B : nullptr, last ? a->val_out + t * B : nullptr,
+                                  last ? a->gen_lens : nullptr, last ? a->done : nullptr, a->end_c, stream);
         if (rc != A4NT_OK) return rc;
     }
     return A4NT_OK;

@@ -70,9 +70,12 @@ struct LstmFwdArgs {
     unsigned* tmo;          // sticky timeout word (sync[32*G] for caller-provided sync blocks)
     int mode;               // 0: persistent sequence sweep, 1: single decode step
     int step0;              // decode: absolute step index (selects the exchange parity)
+    // decode, optional: the previous step's sampler is finished here instead of by proj_gumbel_final_kernel -- tok / val
+    // are then outputs (of step step0 - 1), written by the first workgroup of every row group
+    PgFinalArgs fin;        // fin.part == null: tok / val above are inputs
 };
 
-template <int MT, int NJ>
+template <int MT, int NJ, bool DEC = false>
 __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bid) {
     __shared__ __attribute__((aligned(16))) float part[4][MT][16 * PSTR];
     __shared__ __attribute__((aligned(16))) float hstage[MT][256];
@@ -130,11 +133,11 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bi
         const int rb = r0 + 16 * mt + crow;
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
-            cgv[mt][gt] = (a.mode == 0 && a.cg && rb < a.B) ? a.cg[(long long)rb * H4 + gt * H + u0 + cunit] : 0.f;
+            cgv[mt][gt] = (!DEC && a.cg && rb < a.B) ? a.cg[(long long)rb * H4 + gt * H + u0 + cunit] : 0.f;
     }
 
     int par_r = 0;
-    if (a.mode == 0) {
+    if (!DEC) {
         // publish h0 as "step -1" into parity 0
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) hstage[mt][crow * 16 + cunit] = h_reg[mt];
@@ -151,6 +154,60 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bi
         par_r = a.step0 & 1;
     }
 
+    // decode with a deferred sampler: merge the vocabulary strips of the previous step's projection for this
+    // workgroup's rows (16 lanes per row; the same arithmetic as proj_gumbel_final_kernel, which every workgroup of
+    // the row group repeats -- ~8 strips per lane -- instead of waiting for one more launch)
+    long long tokr[MT];
+    float valr[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { tokr[mt] = 0; valr[mt] = 0.f; }
+    if (DEC) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rb = r0 + 16 * mt + crow;
+            if (a.fin.part) {
+                const PgFinalArgs& f = a.fin;
+                const f32x4* p = reinterpret_cast<const f32x4*>(f.part) + (long long)min(rb, a.B - 1) * f.nstrips;
+                float m = -INFINITY; int mi = 0x7fffffff;
+                for (int s = cunit; s < f.nstrips; s += 16) {
+                    const f32x4 v = p[s];
+                    const float om = v.x; const int oi = __float_as_int(v.z);
+                    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    const float om = __shfl_xor(m, o); const int oi = __shfl_xor(mi, o);
+                    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+                }
+                float hot = 1.0f, s2 = 1.0f;
+                if (!f.greedy) {
+                    float sum = 0.f;
+                    for (int s = cunit; s < f.nstrips; s += 16) {
+                        const f32x4 v = p[s];
+                        if (v.x != -INFINITY) sum += v.y * expf((v.x - m) * f.inv_tau);
+                    }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                    s2 = sum;
+                    const float p_hot = 1.0f / s2;
+                    hot = f.hard ? ((1.0f - p_hot) + p_hot) : p_hot;
+                }
+                tokr[mt] = mi; valr[mt] = hot;
+                if (j == 0 && cunit == 0 && rb < a.B) {
+                    const bool prev_done = f.done ? (f.done[rb] != 0) : false;
+                    if (f.stats) { f.stats[2 * rb] = m; f.stats[2 * rb + 1] = s2; }
+                    f.tok[rb] = mi;
+                    if (f.val_in) f.val_in[rb] = hot;
+                    if (f.val_out) f.val_out[rb] = prev_done ? 0.f : hot;
+                    if (f.gen_lens) f.gen_lens[rb] += prev_done ? 0 : 1;
+                    if (f.done) f.done[rb] = (prev_done || (long long)mi == f.end_c) ? 1 : 0;
+                }
+            } else if (rb < a.B) {
+                tokr[mt] = a.tok[rb]; valr[mt] = a.val[rb];
+            }
+        }
+    }
+
     STAMP_DECL
     for (int t = 0; t < Tg; ++t) {
         const int par_w = par_r ^ 1;
@@ -163,21 +220,21 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bi
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt) xg[mt][gt] = 0.f;
             if (rb < a.B) {
-                if (a.mode == 0) {
+                if (!DEC) {
                     const float* p = a.gx + ((long long)t * a.B + rb) * H4 + u0 + cunit;
 #pragma unroll
                     for (int gt = 0; gt < 4; ++gt) xg[mt][gt] = p[gt * H] + cgv[mt][gt];
                 } else {
                     const float* pc = a.cg + (long long)rb * H4 + u0 + cunit;
-                    const float* pt = a.ptab + a.tok[rb] * (long long)H4 + u0 + cunit;
-                    const float vv = a.val[rb];
+                    const float* pt = a.ptab + tokr[mt] * (long long)H4 + u0 + cunit;
+                    const float vv = valr[mt];
 #pragma unroll
                     for (int gt = 0; gt < 4; ++gt) xg[mt][gt] = pc[gt * H] + vv * pt[gt * H];
                 }
             }
         }
         // (b) wait until every workgroup of the group has published h_{t-1}
-        if (a.mode == 0) {
+        if (!DEC) {
             if (tid == 0) s_ok = wait_ge(ctr, (unsigned)(a.NW * (t + 1)), tmo) ? 1 : 0;
             __syncthreads();
             if (!s_ok) break;
@@ -252,7 +309,7 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bi
         }
         STAMP(6);
         __syncthreads();
-        if (a.mode == 0 && tid == 0) add_flag(ctr, 1u);
+        if (!DEC && tid == 0) add_flag(ctr, 1u);
         STAMP(7);
         // ... then the outputs nobody waits for inside this launch (h_t, saved activations)
 #pragma unroll
@@ -292,7 +349,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) { lstm_fwd
 // the single free-running decoder step (mode = 1) under a name of its own, so that profiles tell the 100 short steps
 // of a generation from the full sweeps
 template <int MT, int NJ>
-__global__ __launch_bounds__(256) void lstm_dec_kernel(LstmFwdArgs a) { lstm_fwd_body<MT, NJ>(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void lstm_dec_kernel(LstmFwdArgs a) { lstm_fwd_body<MT, NJ, true>(a, blockIdx.x); }
 
 // Two independent sweeps in one launch (a4nt_lstm_seq_fwd_pair): workgroups [0, nA) run problem a, the rest
 // problem b, each with its own exchange buffer and counters.  Neither sweep fills the chip alone (128 rows
@@ -980,6 +1037,7 @@ static int launch_seq_fwd(const char* what, int T, int B, int H, const float* gx
     a.gx = gx; a.whh = whh; a.h0 = h0; a.c0 = c0; a.lens = lens;
     a.cg = gc; a.ptab = nullptr; a.tok = nullptr; a.val = nullptr;
     a.hs = hs; a.gates = gates; a.cs = cs; a.hN = hN; a.cN = cN; a.hx = xch; a.sync = sync; a.tmo = tmo; a.mode = 0; a.step0 = 0;
+    a.fin = PgFinalArgs();
     dim3 grid(G * a.NW), block(256);
     A4NT_DISPATCH_LSTM(lstm_fwd_kernel, mt, H / 64, grid, block, s, a);
     return a4nt_check_launch(what);
@@ -1055,14 +1113,14 @@ extern "C" int a4nt_lstm_seq_fwd_noalloc(int T, int B, int H, const float* gx, c
                           tmo, mt, G, s);
 }
 
-extern "C" int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const float* ptab, const long long* tok,
-                                  const float* val, const float* whh, const float* c_prev, float* h_out,
-                                  float* gates_out, float* c_out, float* xch, void* stream) {
+static int launch_dec_step(const char* what, int step, int B, int H, const float* cg, const float* ptab, const long long* tok,
+                           const float* val, const float* whh, const float* c_prev, float* h_out, float* gates_out,
+                           float* c_out, float* xch, const PgFinalArgs& fin, void* stream) {
     int mt, G;
     int rc = a4nt_lstm_geometry(B, H, &mt, &G);
     if (rc != A4NT_OK) return rc;
-    if (!cg || !ptab || !tok || !val || !whh || !h_out || !xch || misaligned(whh) || misaligned(xch)) {
-        a4nt_set_error("a4nt_lstm_dec_step: null or misaligned pointer");
+    if (!cg || !ptab || !whh || !h_out || !xch || misaligned(whh) || misaligned(xch)) {
+        a4nt_set_error("%s: null or misaligned pointer", what);
         return A4NT_ERR_ARG;
     }
     LstmFwdArgs a;
@@ -1071,10 +1129,35 @@ extern "C" int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const
     a.cg = cg; a.ptab = ptab; a.tok = tok; a.val = val;
     a.hs = h_out; a.gates = gates_out; a.cs = c_out; a.hN = nullptr; a.cN = nullptr; a.hx = xch; a.sync = nullptr; a.tmo = nullptr;
     a.mode = 1; a.step0 = step;
+    a.fin = fin;
     dim3 grid(G * a.NW), block(256);
     hipStream_t s = (hipStream_t)stream;
     A4NT_DISPATCH_LSTM(lstm_dec_kernel, mt, H / 64, grid, block, s, a);
-    return a4nt_check_launch("lstm_dec_step");
+    return a4nt_check_launch(what);
+}
+
+extern "C" int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const float* ptab, const long long* tok,
+                                  const float* val, const float* whh, const float* c_prev, float* h_out,
+                                  float* gates_out, float* c_out, float* xch, void* stream) {
+    if (!tok || !val) { a4nt_set_error("a4nt_lstm_dec_step: null tok / val"); return A4NT_ERR_ARG; }
+    return launch_dec_step("a4nt_lstm_dec_step", step, B, H, cg, ptab, tok, val, whh, c_prev, h_out, gates_out, c_out, xch,
+                           PgFinalArgs(), stream);
+}
+
+extern "C" int a4nt_lstm_dec_step_merge(int step, int B, int H, const float* cg, const float* ptab, const float* whh,
+                                        const float* c_prev, float* h_out, float* gates_out, float* c_out, float* xch,
+                                        int V, const float* part, float tau, int hard, int greedy, float* stats,
+                                        long long* tok, float* val_in, float* val_out, int* gen_lens, unsigned char* done,
+                                        long long end_c, void* stream) {
+    if (V <= 0 || !part || !tok || (!greedy && tau <= 0.f) || (reinterpret_cast<uintptr_t>(part) & 15)) {
+        a4nt_set_error("a4nt_lstm_dec_step_merge: bad sampler arguments (V=%d, tau=%g, part 16-byte aligned)", V, (double)tau);
+        return A4NT_ERR_ARG;
+    }
+    PgFinalArgs f;
+    f.part = part; f.nstrips = (V + PG_BC - 1) / PG_BC; f.inv_tau = greedy ? 1.f : 1.f / tau; f.greedy = greedy; f.hard = hard;
+    f.stats = stats; f.tok = tok; f.val_in = val_in; f.val_out = val_out; f.gen_lens = gen_lens; f.done = done; f.end_c = end_c;
+    return launch_dec_step("a4nt_lstm_dec_step_merge", step, B, H, cg, ptab, nullptr, nullptr, whh, c_prev, h_out, gates_out, c_out,
+                           xch, f, stream);
 }
 
 extern "C" int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const float* gates, const float* cs,
@@ -1165,6 +1248,7 @@ extern "C" int a4nt_lstm_seq_fwd_pair(int H, const a4nt_lstm_fwd_problem* p0, co
         q.cg = p[i]->gc; q.ptab = nullptr; q.tok = nullptr; q.val = nullptr;
         q.hs = p[i]->hs; q.gates = p[i]->gates; q.cs = p[i]->cs; q.hN = p[i]->hN; q.cN = p[i]->cN; q.hx = p[i]->xch;
         q.sync = p[i]->sync; q.tmo = p[i]->sync + 32 * G[i]; q.mode = 0; q.step0 = 0;
+        q.fin = PgFinalArgs();
     }
     const int nA = G[0] * (H / 16);
     dim3 grid((G[0] + G[1]) * (H / 16)), block(256);

@@ -48,8 +48,10 @@ extern "C" int a4nt_embed_bwd(long long N, int E, int V, const long long* ids, c
     return a4nt_check_launch("embed_bwd");
 }
 
-// out[n] (+)= sum_m A[m][n]
-__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* A, int lda, float* out, int rows_per) {
+// out[n] (+)= sum_m A[m][n].  Deterministic: the row chunks of a column block write partial sums into a workspace
+// ([chunks][N]) and a second launch adds them in chunk order (no atomics: the same bits on every run).
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* A, int lda, float* part, int rows_per,
+                                                     int direct, int accumulate) {
     // one workgroup = 256 columns x rows_per rows: lane l of every wave owns columns 4l..4l+3 of the block (one 16-byte
     // load per row when the row is 16-byte aligned, 1 KB per wave instruction), the 4 waves take every 4th row
     __shared__ float red[4][256];
@@ -75,19 +77,48 @@ __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* 
     red[w][4 * lane] = s0; red[w][4 * lane + 1] = s1; red[w][4 * lane + 2] = s2; red[w][4 * lane + 3] = s3;
     __syncthreads();
     const int cc = blockIdx.x * 256 + threadIdx.x;
-    if (cc < N) atomicAdd(&out[cc], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (cc >= N) return;
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (direct) part[cc] = (accumulate ? part[cc] : 0.f) + v;          // a single chunk: `part` is the output itself
+    else part[(long long)blockIdx.y * N + cc] = v;
 }
-extern "C" int a4nt_colsum(int M, int N, const float* A, int lda, float* out, int accumulate, void* stream) {
+__global__ void colsum_finish_kernel(int N, int chunks, const float* part, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = accumulate ? out[c] : 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(long long)k * N + c];
+    out[c] = s;
+}
+static int colsum_chunks(int M, int N) {
+    const int cb = (N + 255) / 256;
+    return max(1, min((M + 31) / 32, 2048 / cb));
+}
+extern "C" long long a4nt_colsum_ws_floats(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    const int chunks = colsum_chunks(M, N);
+    return chunks > 1 ? (long long)chunks * N : 0;
+}
+extern "C" int a4nt_colsum(int M, int N, const float* A, int lda, float* out, int accumulate, float* ws,
+                           long long ws_floats, void* stream) {
     if (N <= 0) return A4NT_OK;
     if (!A || !out || M < 0) { a4nt_set_error("a4nt_colsum: bad arguments"); return A4NT_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * 4, s) != hipSuccess) return a4nt_check_launch("colsum memset");
-    if (M == 0) return A4NT_OK;
+    if (M == 0) {
+        if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * 4, s) != hipSuccess) return a4nt_check_launch("colsum memset");
+        return A4NT_OK;
+    }
     const int cb = (N + 255) / 256;
-    int chunks = max(1, min((M + 31) / 32, 2048 / cb));
+    int chunks = colsum_chunks(M, N);
+    if (!ws) chunks = 1;                                   // no workspace: one workgroup per column block (slow, still exact)
+    else if (ws_floats < (long long)chunks * N) chunks = (int)max(1ll, ws_floats / N);
     const int rows_per = (M + chunks - 1) / chunks;
     chunks = (M + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cb, chunks), dim3(256), 0, s, M, N, A, lda, out, rows_per);
+    if (chunks == 1) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cb, 1), dim3(256), 0, s, M, N, A, lda, out, rows_per, 1, accumulate ? 1 : 0);
+        return a4nt_check_launch("colsum");
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3(cb, chunks), dim3(256), 0, s, M, N, A, lda, ws, rows_per, 0, 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, chunks, ws, out, accumulate ? 1 : 0);
     return a4nt_check_launch("colsum");
 }
 

@@ -26,7 +26,6 @@
 // the logits never make a round trip through HBM.
 #include "gemm_stage.h"
 
-#define PG_BC 80          // strip width: five 16-column MFMA tiles per wave
 #define PG_DEPTH 8        // 16-k blocks in flight per wave
 
 struct ProjGumbelArgs {
@@ -277,11 +276,8 @@ __global__ __launch_bounds__(256 * (1 + NW)) void proj_gumbel_kernel(ProjGumbelA
     }
 }
 
-// Merge the strips of one row (online-softmax merge), then the sampler's bookkeeping.
-struct PgFinalArgs {
-    const float* part; int nstrips; float inv_tau; int greedy; int hard;
-    float* stats; long long* tok; float* val_in; float* val_out; int* gen_lens; unsigned char* done; long long end_c;
-};
+// Merge the strips of one row (online-softmax merge), then the sampler's bookkeeping (PgFinalArgs: common.h; the
+// decoder step kernel of lstm.hip does the same merge in its prologue when the finalisation is deferred to it).
 __global__ __launch_bounds__(64) void proj_gumbel_final_kernel(PgFinalArgs a) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const float* p = a.part + (long long)b * a.nstrips * 4;
@@ -360,7 +356,7 @@ extern "C" int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh
                                     float* stats, long long* tok, float* val_in, float* val_out, int* gen_lens,
                                     unsigned char* done, long long end_c, void* stream) {
     if (M <= 0) return A4NT_OK;
-    if (N <= 0 || K <= 0 || (K & 15) || !h || !W || !part || !tok || (!greedy && tau <= 0.f) ||
+    if (N <= 0 || K <= 0 || (K & 15) || !h || !W || !part || (!greedy && tau <= 0.f) ||
         (reinterpret_cast<uintptr_t>(h) & 15) || (ldh & 3)) {
         a4nt_set_error("a4nt_proj_gumbel_fwd: bad arguments (N=%d, K=%d must be a multiple of 16, tau=%g, h 16-byte "
                        "aligned with ldh a multiple of 4)", N, K, (double)tau);
@@ -383,10 +379,21 @@ extern "C" int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh
     else         { if (packed) { if (nw) PG_LAUNCH(2, true, 1); else PG_LAUNCH(2, true, 0); } else { if (nw) PG_LAUNCH(2, false, 1); else PG_LAUNCH(2, false, 0); } }
 #undef PG_LAUNCH
     int rc = a4nt_check_launch("proj_gumbel");
-    if (rc != A4NT_OK) return rc;
+    if (rc != A4NT_OK || !tok) return rc;            // tok == null: the strips stay in `part` for a later finalisation
+    return a4nt_proj_gumbel_finalize(M, N, part, tau, hard, greedy, stats, tok, val_in, val_out, gen_lens, done, end_c, stream);
+}
+
+extern "C" int a4nt_proj_gumbel_finalize(int M, int N, const float* part, float tau, int hard, int greedy, float* stats,
+                                         long long* tok, float* val_in, float* val_out, int* gen_lens, unsigned char* done,
+                                         long long end_c, void* stream) {
+    if (M <= 0) return A4NT_OK;
+    if (N <= 0 || !part || !tok || (!greedy && tau <= 0.f)) {
+        a4nt_set_error("a4nt_proj_gumbel_finalize: bad arguments (N=%d, tau=%g)", N, (double)tau);
+        return A4NT_ERR_ARG;
+    }
     PgFinalArgs f;
-    f.part = part; f.nstrips = a.nstrips; f.inv_tau = a.inv_tau; f.greedy = greedy; f.hard = hard; f.stats = stats;
-    f.tok = tok; f.val_in = val_in; f.val_out = val_out; f.gen_lens = gen_lens; f.done = done; f.end_c = end_c;
-    hipLaunchKernelGGL(proj_gumbel_final_kernel, dim3(M), dim3(64), 0, s, f);
+    f.part = part; f.nstrips = (N + PG_BC - 1) / PG_BC; f.inv_tau = greedy ? 1.f : 1.f / tau; f.greedy = greedy; f.hard = hard;
+    f.stats = stats; f.tok = tok; f.val_in = val_in; f.val_out = val_out; f.gen_lens = gen_lens; f.done = done; f.end_c = end_c;
+    hipLaunchKernelGGL(proj_gumbel_final_kernel, dim3(M), dim3(64), 0, (hipStream_t)stream, f);
     return a4nt_check_launch("proj_gumbel_final");
 }

@@ -253,7 +253,9 @@ def colsum(A, out=None, accumulate=False):
     if out is None:
         out = torch.empty(N, device=A.device, dtype=torch.float32)
         accumulate = False
-    check(lib.a4nt_colsum(M, N, _p(A), _ld(A), _p(out), int(accumulate), _s()), 'a4nt_colsum')
+    nws = int(lib.a4nt_colsum_ws_floats(M, N))
+    ws = torch.empty(nws, device=A.device, dtype=torch.float32) if nws else None
+    check(lib.a4nt_colsum(M, N, _p(A), _ld(A), _p(out), int(accumulate), _p(ws), nws, _s()), 'a4nt_colsum')
     return out
 
 

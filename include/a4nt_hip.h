@@ -160,6 +160,17 @@ int a4nt_lstm_check_timeout(const unsigned* sync, int groups, void* stream);
 int a4nt_lstm_dec_step(int step, int B, int H, const float* cg, const float* ptab, const long long* tok,
                        const float* val, const float* whh, const float* c_prev, float* h_out, float* gates_out,
                        float* c_out, float* xch, void* stream);
+/* The same step with the PREVIOUS step's sampler finished in its prologue: a4nt_proj_gumbel_fwd(tok = NULL) left
+ * the per-strip partials of that step in `part`; every workgroup merges the strips of its own 16 rows (the
+ * arithmetic of a4nt_proj_gumbel_finalize) to get the token and the straight-through value it needs, and the first
+ * workgroup of each row group writes the step's results (stats, tok, val_in, val_out, gen_lens, done: the
+ * arguments of a4nt_proj_gumbel_finalize, all for step - 1).  Saves one launch per decoding step.
+ * Replaces: the same lines as a4nt_lstm_dec_step plus the bookkeeping of char_translator.py:384-392. */
+int a4nt_lstm_dec_step_merge(int step, int B, int H, const float* cg, const float* ptab, const float* whh,
+                             const float* c_prev, float* h_out, float* gates_out, float* c_out, float* xch, int V,
+                             const float* part, float tau, int hard, int greedy, float* stats, long long* tok,
+                             float* val_in, float* val_out, int* gen_lens, unsigned char* done, long long end_c,
+                             void* stream);
 
 /* The free-running decoder's host loops in native code: steps [t0, t1) of the generation loop
  * (a4nt_lstm_dec_step + a4nt_proj_gumbel_fwd per step) and the whole reverse loop of its backward pass (per step,
@@ -239,6 +250,12 @@ int a4nt_proj_gumbel_fwd(int M, int N, int K, const float* h, int ldh, const flo
                          float* stats,
                          long long* tok, float* val_in, float* val_out, int* gen_lens, unsigned char* done,
                          long long end_c, void* stream);
+/* The finalisation alone (merge of the strips in `part` + the bookkeeping above).  a4nt_proj_gumbel_fwd runs it
+ * unless tok is NULL; then the caller finishes the step later, with this call or inside the next decoder step
+ * (a4nt_lstm_dec_step_merge).  N = the projection's column count (it fixes the number of strips). */
+int a4nt_proj_gumbel_finalize(int M, int N, const float* part, float tau, int hard, int greedy, float* stats,
+                              long long* tok, float* val_in, float* val_out, int* gen_lens, unsigned char* done,
+                              long long end_c, void* stream);
 
 /* Log-softmax + NLL over N rows of logits that some other producer wrote (no statistics available): leaves
  * (softmax - onehot)*gscale in place of the logits when write_grad.  target < 0 ignores the row.
@@ -270,8 +287,13 @@ int a4nt_embed_fwd(long long N, int E, int V, const long long* ids, const float*
 int a4nt_embed_bwd(long long N, int E, int V, const long long* ids, const float* scale, const float* dout, int ldd,
                    float* dW, long long padding_idx, void* stream);
 
-/* out[n] (+)= sum_m A[m][n]  (bias gradients). */
-int a4nt_colsum(int M, int N, const float* A, int lda, float* out, int accumulate, void* stream);
+/* out[n] (+)= sum_m A[m][n]  (bias gradients: the .sum(0) autograd takes for an nn.Linear / nn.LSTM bias,
+ * char_translator.py:279, char_lstm.py:148).  Deterministic: row chunks write partial sums into `ws`
+ * (a4nt_colsum_ws_floats(M, N) floats of device memory, contents undefined before and after) and a second
+ * launch adds them in chunk order.  ws may be null or smaller: fewer chunks, slower, the same kind of result. */
+long long a4nt_colsum_ws_floats(int M, int N);
+int a4nt_colsum(int M, int N, const float* A, int lda, float* out, int accumulate, float* ws, long long ws_floats,
+                void* stream);
 /* out[r][c] = sum_s slabs[s*stride + r*lds + c0 + c] (+ add[r][c])  (split-K reduction). */
 int a4nt_slab_reduce(int S, long long stride, int R, int C, const float* slabs, int lds, int c0, const float* add,
                      int lda, float* out, int ldo, void* stream);

@@ -264,12 +264,19 @@ class CharTranslator(nn.Module):
         else:
             r0, r1 = grad_rows
             assert compact and not soft_in and h_prev is None and 0 <= r0 < r1 <= B
-            parts = []
-            for a_, b_, grad in ((0, r0, False), (r0, r1, True), (r1, B, False)):
-                if b_ > a_:
-                    with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
-                        parts.append(self._gen_context(x[:, a_:b_], lengths_inp[a_:b_], None, False, auths[a_:b_]))
-            ctxt = torch.cat(parts, dim=0)
+            outer = torch.is_grad_enabled()
+
+            def part(a_, b_, grad):
+                with torch.set_grad_enabled(grad and outer):
+                    return self._gen_context(x[:, a_:b_], lengths_inp[a_:b_], None, False, auths[a_:b_])
+            spans = [(a_, b_, g_) for a_, b_, g_ in ((0, r0, False), (r0, r1, True), (r1, B, False)) if b_ > a_]
+            if len(spans) == 2:
+                # the two encoder passes (rows encoded without a graph, rows that will be differentiated) do not use
+                # each other's results: their LSTM layers share launches (ops.paired)
+                parts = ops.paired(lambda: part(*spans[0]), lambda: part(*spans[1]))
+            else:
+                parts = [part(*sp) for sp in spans]
+            ctxt = torch.cat(list(parts), dim=0)
         if soft_samples:
             self.temp = temp
         dec = self._decoder(auths)

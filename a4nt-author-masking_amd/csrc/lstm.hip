@@ -91,6 +91,76 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bi
     const int fr = lane & 15, fq = lane >> 4;      // MFMA fragment row/col and k-quad
     const int crow = tid >> 4, cunit = tid & 15;   // cell-update (row, unit) of this thread
 
+    // decode with a deferred sampler: merge the vocabulary strips of the previous step's projection for this
+    // workgroup's rows (16 lanes per row, 8 strips per lane and pass, all loads of a pass in flight together; the
+    // arithmetic of proj_gumbel_final_kernel, which every workgroup of the row group repeats instead of waiting for
+    // one more launch).  Placed ahead of the weight loads so that both latencies overlap.
+    long long tokr[MT];
+    float valr[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { tokr[mt] = 0; valr[mt] = 0.f; }
+    if (DEC) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rb = r0 + 16 * mt + crow;
+            if (a.fin.part) {
+                const PgFinalArgs& f = a.fin;
+                const f32x4* p = reinterpret_cast<const f32x4*>(f.part) + (long long)min(rb, a.B - 1) * f.nstrips;
+                const int npass = (f.nstrips + 127) >> 7;
+                f32x4 v[8];
+                auto load_pass = [&](int ps) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int s = 128 * ps + 16 * u + cunit;
+                        v[u] = p[min(s, f.nstrips - 1)];
+                        if (s >= f.nstrips) { v[u].x = -INFINITY; v[u].y = 0.f; v[u].z = __int_as_float(0x7fffffff); }
+                    }
+                };
+                float m = -INFINITY; int mi = 0x7fffffff;
+                for (int ps = npass - 1; ps >= 0; --ps) {           // pass 0 last: its strips stay in registers
+                    load_pass(ps);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float om = v[u].x; const int oi = __float_as_int(v[u].z);
+                        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+                    }
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    const float om = __shfl_xor(m, o); const int oi = __shfl_xor(mi, o);
+                    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+                }
+                float hot = 1.0f, s2 = 1.0f;
+                if (!f.greedy) {
+                    float sum = 0.f;
+                    for (int ps = 0; ps < npass; ++ps) {
+                        if (ps > 0) load_pass(ps);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (v[u].x != -INFINITY) sum += v[u].y * expf((v[u].x - m) * f.inv_tau);
+                    }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                    s2 = sum;
+                    const float p_hot = 1.0f / s2;
+                    hot = f.hard ? ((1.0f - p_hot) + p_hot) : p_hot;
+                }
+                tokr[mt] = mi; valr[mt] = hot;
+                if (j == 0 && cunit == 0 && rb < a.B) {
+                    const bool prev_done = f.done ? (f.done[rb] != 0) : false;
+                    if (f.stats) { f.stats[2 * rb] = m; f.stats[2 * rb + 1] = s2; }
+                    f.tok[rb] = mi;
+                    if (f.val_in) f.val_in[rb] = hot;
+                    if (f.val_out) f.val_out[rb] = prev_done ? 0.f : hot;
+                    if (f.gen_lens) f.gen_lens[rb] += prev_done ? 0 : 1;
+                    if (f.done) f.done[rb] = (prev_done || (long long)mi == f.end_c) ? 1 : 0;
+                }
+            } else if (rb < a.B) {
+                tokr[mt] = a.tok[rb]; valr[mt] = a.val[rb];
+            }
+        }
+    }
+
     // ---- recurrent weights -> registers --------------------------------------------------
     f32x4 wreg[NJ][4];
 #pragma unroll
@@ -152,60 +222,6 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bi
         if (tid == 0) add_flag(ctr, 1u);
     } else {
         par_r = a.step0 & 1;
-    }
-
-    // decode with a deferred sampler: merge the vocabulary strips of the previous step's projection for this
-    // workgroup's rows (16 lanes per row; the same arithmetic as proj_gumbel_final_kernel, which every workgroup of
-    // the row group repeats -- ~8 strips per lane -- instead of waiting for one more launch)
-    long long tokr[MT];
-    float valr[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { tokr[mt] = 0; valr[mt] = 0.f; }
-    if (DEC) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int rb = r0 + 16 * mt + crow;
-            if (a.fin.part) {
-                const PgFinalArgs& f = a.fin;
-                const f32x4* p = reinterpret_cast<const f32x4*>(f.part) + (long long)min(rb, a.B - 1) * f.nstrips;
-                float m = -INFINITY; int mi = 0x7fffffff;
-                for (int s = cunit; s < f.nstrips; s += 16) {
-                    const f32x4 v = p[s];
-                    const float om = v.x; const int oi = __float_as_int(v.z);
-                    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
-                }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    const float om = __shfl_xor(m, o); const int oi = __shfl_xor(mi, o);
-                    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
-                }
-                float hot = 1.0f, s2 = 1.0f;
-                if (!f.greedy) {
-                    float sum = 0.f;
-                    for (int s = cunit; s < f.nstrips; s += 16) {
-                        const f32x4 v = p[s];
-                        if (v.x != -INFINITY) sum += v.y * expf((v.x - m) * f.inv_tau);
-                    }
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-                    s2 = sum;
-                    const float p_hot = 1.0f / s2;
-                    hot = f.hard ? ((1.0f - p_hot) + p_hot) : p_hot;
-                }
-                tokr[mt] = mi; valr[mt] = hot;
-                if (j == 0 && cunit == 0 && rb < a.B) {
-                    const bool prev_done = f.done ? (f.done[rb] != 0) : false;
-                    if (f.stats) { f.stats[2 * rb] = m; f.stats[2 * rb + 1] = s2; }
-                    f.tok[rb] = mi;
-                    if (f.val_in) f.val_in[rb] = hot;
-                    if (f.val_out) f.val_out[rb] = prev_done ? 0.f : hot;
-                    if (f.gen_lens) f.gen_lens[rb] += prev_done ? 0 : 1;
-                    if (f.done) f.done[rb] = (prev_done || (long long)mi == f.end_c) ? 1 : 0;
-                }
-            } else if (rb < a.B) {
-                tokr[mt] = a.tok[rb]; valr[mt] = a.val[rb];
-            }
-        }
     }
 
     STAMP_DECL

@@ -82,12 +82,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* 
     if (direct) part[cc] = (accumulate ? part[cc] : 0.f) + v;          // a single chunk: `part` is the output itself
     else part[(long long)blockIdx.y * N + cc] = v;
 }
-__global__ void colsum_finish_kernel(int N, int chunks, const float* part, float* out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    float s = accumulate ? out[c] : 0.f;
-    for (int k = 0; k < chunks; ++k) s += part[(long long)k * N + c];
-    out[c] = s;
+// 64 columns x 4 chunk groups per workgroup: group q adds chunks q, q+4, ... (independent loads in flight), the four
+// group sums are added in a fixed order
+__global__ __launch_bounds__(256) void colsum_finish_kernel(int N, int chunks, const float* part, float* out, int accumulate) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < N) {
+        int k = q;
+        for (; k + 4 < chunks; k += 8) {
+            s0 += part[(long long)k * N + c];
+            s1 += part[(long long)(k + 4) * N + c];
+        }
+        if (k < chunks) s0 += part[(long long)k * N + c];
+    }
+    red[q][cl] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && c < N) out[c] = (accumulate ? out[c] : 0.f) + ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 static int colsum_chunks(int M, int N) {
     const int cb = (N + 255) / 256;
@@ -118,7 +130,7 @@ extern "C" int a4nt_colsum(int M, int N, const float* A, int lda, float* out, in
         return a4nt_check_launch("colsum");
     }
     hipLaunchKernelGGL(colsum_kernel, dim3(cb, chunks), dim3(256), 0, s, M, N, A, lda, ws, rows_per, 0, 0);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, chunks, ws, out, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, s, N, chunks, ws, out, accumulate ? 1 : 0);
     return a4nt_check_launch("colsum");
 }
 

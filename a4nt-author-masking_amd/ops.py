@@ -672,9 +672,16 @@ class _LstmLayerPair(Function):
             reqs.append((w_hh.contiguous(), gates, cs, c0 if has_c0 else None, lens_dev if has_lens else None, dout,
                          dhN, dcN, need_h0))
             info.append((x2, w_ih, hs_all, T, B, I, H, has_c0, has_gc, has_h0, nig))
-        res = lstm_seq_bwd_pair(reqs)
+        need = [any(ctx.needs_input_grad[9 * k:9 * k + 9]) for k in range(2)]
+        if need[0] and need[1]:
+            res = lstm_seq_bwd_pair(reqs)
+        else:                       # one side was run without a graph (mixed pair): only the other one has a backward sweep
+            res = [lstm_seq_bwd(*reqs[k]) if need[k] else None for k in range(2)]
         grads = []
         for k in range(2):
+            if not need[k]:
+                grads += [None] * 9
+                continue
             dgates, dh0, dc0 = res[k]
             x2, w_ih, hs_all, T, B, I, H, has_c0, has_gc, has_h0, nig = info[k]
             dG2 = dgates.view(T * B, 4 * H)
@@ -697,6 +704,7 @@ class _PairScheduler:
         self.turn = 0
         self.done = [False, False]
         self.pending = [None, None]
+        self.grad = [True, True]          # grad mode of each side at its pending request
         self.result = [None, None]
         self.error = [None, None]
 
@@ -712,7 +720,18 @@ class _PairScheduler:
             if self._other_waiting(me):
                 a = (args, self.pending[other]) if me == 0 else (self.pending[other], args)
                 if _pairable(a[0], a[1]):
-                    outs = _LstmLayerPair.apply(*(a[0] + a[1]))
+                    gm = [False, False]
+                    gm[me], gm[other] = torch.is_grad_enabled(), self.grad[other]
+                    if gm[0] == gm[1]:
+                        outs = _LstmLayerPair.apply(*(a[0] + a[1]))
+                    else:
+                        # one side runs without a graph: its inputs enter detached (no gradients, no backward sweep for
+                        # it) and its outputs leave detached; the other side's graph is recorded as usual
+                        det = lambda tup: tuple(t.detach() if torch.is_tensor(t) else t for t in tup)
+                        a = tuple(a[k] if gm[k] else det(a[k]) for k in range(2))
+                        with torch.enable_grad():
+                            outs = _LstmLayerPair.apply(*(a[0] + a[1]))
+                        outs = tuple(o if gm[i // 3] else o.detach() for i, o in enumerate(outs))
                     mine, theirs = (outs[:3], outs[3:]) if me == 0 else (outs[3:], outs[:3])
                     self.pending[other] = None
                     self.result[other] = theirs
@@ -722,6 +741,7 @@ class _PairScheduler:
                 self.result[other] = 'solo'
             # hand the baton over with my request pending
             self.pending[me] = args
+            self.grad[me] = torch.is_grad_enabled()
             self.turn = other
             self.cv.notify_all()
             while self.turn != me:

@@ -285,6 +285,43 @@ def test_lstm_paired_equals_sequential(ops, H, B0, B1, T0, T1, wgs):
         ops.lstm_set_max_workgroups(512)
 
 
+def test_lstm_paired_mixed_grad(ops):
+    """One side of a pair runs without a graph (the rows of the fused update's generation that are not
+    differentiated): it returns detached results and adds nothing to the shared weights' gradients, the other side's
+    results and gradients are those of running it alone."""
+    H, I, T, B = 64, 16, 5, 12
+    P = _stack_params(I, H, 400)
+    xa, xb = _rand(T, B, I, seed=41).cuda(), _rand(T, B, I, seed=42).cuda().requires_grad_(True)
+    up = _rand(T, B, H, seed=43).cuda()
+
+    def nograd():
+        with torch.no_grad():
+            return _stack_loss(ops, P, xa, None, up)
+
+    def grad():
+        return _stack_loss(ops, P, xb, None, up)
+
+    res = {}
+    for mode in ('seq', 'pair', 'pair_swapped'):
+        for v in list(P.values()) + [xb]:
+            v.grad = None
+        ops.PAIR_LSTM = mode != 'seq'
+        try:
+            if mode == 'pair_swapped':
+                lg, ln = ops.paired(grad, nograd)
+            else:
+                ln, lg = ops.paired(nograd, grad)
+        finally:
+            ops.PAIR_LSTM = True
+        assert not ln.requires_grad and lg.requires_grad
+        lg.backward()
+        res[mode] = [ln.detach(), lg.detach(), xb.grad.clone()] + [P[k].grad.clone() for k in sorted(P)]
+    ops.check_timeouts()
+    for mode in ('pair', 'pair_swapped'):
+        for a, b in zip(res['seq'], res[mode]):
+            assert torch.equal(a, b), mode
+
+
 def test_lstm_paired_uneven_and_errors(ops):
     """One side has three layers, the other one; a side that raises surfaces in the caller."""
     H, I, T, B = 64, 16, 4, 6

@@ -48,7 +48,7 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
     len_sorted, sort_idx = gl_host.sort(dim=0, descending=True, stable=True)
     _, rev_sort_idx = sort_idx.sort(dim=0)
     dev = samples.val.device
-    sort_dev, rev_dev = sort_idx.to(dev), rev_sort_idx.to(dev)
+    sort_dev, rev_dev = ops.h2d(sort_idx, dev), ops.h2d(rev_sort_idx, dev)
     samples_srt = samples.index_select_batch(sort_dev)
     if backprop_for == 'eval':
         samples_srt = samples_srt.detach()
@@ -108,9 +108,9 @@ def _sorted_encode(encoder, samples, lens_dev, start_id):
     len_sorted, sort_idx = gl.sort(dim=0, descending=True, stable=True)
     _, rev_idx = sort_idx.sort(dim=0)
     dev = samples.val.device
-    enc_inp = samples.index_select_batch(sort_idx.to(dev)).prepend_token(start_id)
+    enc_inp = samples.index_select_batch(ops.h2d(sort_idx, dev)).prepend_token(start_id)
     rev_enc = encoder.forward_encode(enc_inp, len_sorted.tolist(), adv_inp=True)
-    return rev_enc.index_select(0, rev_idx.to(dev))
+    return rev_enc.index_select(0, ops.h2d(rev_idx, dev))
 
 
 def gan_generator_loss(logits, targ_aid, wasserstein=False, maximize_entropy=0, sample_weight=None):
@@ -141,7 +141,7 @@ def _language_model_ce(lang_model, lang_map, samples, lens_dev, start_id):
     gl = lens_dev.cpu()
     len_sorted, sort_idx = gl.sort(dim=0, descending=True, stable=True)
     dev = samples.val.device
-    enc_inp = samples.index_select_batch(sort_idx.to(dev)).prepend_token(start_id)
+    enc_inp = samples.index_select_batch(ops.h2d(sort_idx, dev)).prepend_token(start_id)
     from .gen_decode import mapped
     ll = len_sorted.tolist()
     lm_inp = mapped(enc_inp, lang_map)                   # rows = one_hot(tok) * val @ lang_map, never materialised
@@ -312,7 +312,7 @@ class GradAllReducer(object):
         mean over the GLOBAL token count (ragged batches: ranks hold different numbers of valid tokens)."""
         if not self.on:
             return 1.0
-        t = torch.tensor(float(n_local), device=self.params[0].device)
+        t = ops.h2d(float(n_local), self.params[0].device, torch.float32)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return (float(n_local) * self.world) / t          # stays on the device: no host sync
 
@@ -453,7 +453,7 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
     elif cycle_loss_type == 'bow':
         rev, rev_lens, rev_chars = outs[-3], outs[-2], outs[-1]
         cyc_targ = torch.zeros(targs.shape[1], rev.vocab, device=dev).scatter_add_(
-            1, targs.t().to(dev), torch.ones(targs.shape[::-1], device=dev))
+            1, ops.h2d(targs.t().contiguous(), dev), torch.ones(targs.shape[::-1], device=dev))
         cyc_targ[:, 0] = 0
         cyc_loss = cycle_loss_w * loss_fn(rev.to_dense().sum(dim=0), cyc_targ)
         rev_out = (rev_lens, rev_chars)

@@ -168,9 +168,9 @@ class CharTranslator(nn.Module):
             else:
                 ctxt = enc_hidden[0][-1]
             if sort_enc is not None:
-                ctxt = ctxt.index_select(0, sort_enc.to(dev))
+                ctxt = ctxt.index_select(0, ops.h2d(sort_enc, dev))
             if self.pad_auth_vec:
-                ctxt = torch.cat([ctxt, self.auth_emb(auths.to(dev))], dim=-1)
+                ctxt = torch.cat([ctxt, self.auth_emb(ops.h2d(auths, dev))], dim=-1)
             if self.enc_noise:
                 ctxt = ctxt + torch.randn(ctxt.shape, device=dev) / 20.       # char_translator.py:240-241
             else:
@@ -222,10 +222,10 @@ class CharTranslator(nn.Module):
         dec_out, n_t, B, _, W_out, b_out = self._mltrain_hidden(inp, lengths_inp, targ_in, lengths_targ, h_prev, auths,
                                                                 adv_inp, sort_enc)
         dev = self._dev()
-        tgt = targ_out[:n_t].to(dev).clone()
+        tgt = ops.h2d(targ_out[:n_t], dev).clone()
         steps = torch.arange(n_t, device=dev).view(-1, 1)
-        lens_t = torch.as_tensor([int(l) for l in lengths_targ], device=dev).view(1, -1)
-        tgt[steps >= lens_t] = -1
+        lens_t = ops.h2d([int(l) for l in lengths_targ], dev).view(1, -1)
+        tgt.masked_fill_(steps >= lens_t, -1)
         n_valid = int(sum(min(int(l), n_t) for l in lengths_targ))
         return ops.proj_nll(dec_out.reshape(n_t * B, -1), W_out, b_out, tgt.view(-1), n_valid)
 
@@ -248,7 +248,7 @@ class CharTranslator(nn.Module):
         else:
             ctxt = enc_hidden[0][-1]
         if self.pad_auth_vec:
-            ctxt = torch.cat([ctxt, self.auth_emb(auths.to(self._dev()))], dim=-1)
+            ctxt = torch.cat([ctxt, self.auth_emb(ops.h2d(auths, self._dev()))], dim=-1)
         return ctxt
 
     def forward_advers_gen(self, x, lengths_inp, h_prev=None, n_max=100, end_c=-1, soft_samples=False, temp=0.1,

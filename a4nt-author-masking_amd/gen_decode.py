@@ -285,8 +285,13 @@ class _GenDecode(Function):
                 ev.record()
                 pending = (ev, flag)
         # the one read-back of a generation: every later consumer of the lengths (the length sort, the row split of
-        # fused_update) takes this host copy (ops.host_lens) instead of draining the GPU again
-        gl_host = gen_lens.cpu()
+        # fused_update) takes this host copy (ops.host_lens) instead of draining the GPU again.  Without an end token
+        # (end_c < 0, the reference's default) no row can finish early: every length is n_max, known without asking
+        # the GPU, and the host keeps running ahead of it through the whole training step.
+        if cfg['end_c'] < 0:
+            gl_host = torch.full((B,), ran, dtype=torch.int32)
+        else:
+            gl_host = gen_lens.cpu()
         holder['lens_host'] = gl_host
         n_out = int(gl_host.max())                  # = steps the reference loop would have run
         n_out = max(1, min(n_out, ran))

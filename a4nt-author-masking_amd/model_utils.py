@@ -69,7 +69,7 @@ def reverse_time(x, lens, T):
     flipped, the padding stays where it is).  Its own inverse.  lens None: every row has T steps."""
     if lens is None:
         return x.flip(0)
-    l = torch.as_tensor([int(v) for v in lens], device=x.device).view(1, -1)
+    l = ops.h2d([int(v) for v in lens], x.device).view(1, -1)
     t = torch.arange(T, device=x.device).view(-1, 1)
     idx = torch.where(t < l, l - 1 - t, t)                                     # [T,B]
     return x.gather(0, idx.unsqueeze(-1).expand(-1, -1, x.shape[2]))
@@ -99,10 +99,9 @@ def run_stack_bidir(rec, x, lens, depth, h_prev=None):
 
 def ids_to_device(x, device):
     """Token ids (CPU int64, as the callers hand them over: char_translator.py:208, char_lstm.py:273) -> device.
-    non_blocking: from the pinned staging tensors of data_provider.prepare_data this is an asynchronous DMA the host
-    does not wait for (torch's pinned-memory allocator keeps the block until the copy's event has passed); from
-    pageable memory torch stages the copy itself."""
-    return x if x.device == device else x.to(device, non_blocking=True)
+    Asynchronous (ops.h2d): from the pinned staging tensors of data_provider.prepare_data a DMA the host does not wait
+    for; pageable tensors are staged through a pinned copy first."""
+    return ops.h2d(x, device)
 
 
 def lens_to_device(lens, T, device):
@@ -110,10 +109,10 @@ def lens_to_device(lens, T, device):
     if lens is None:
         return None
     if torch.is_tensor(lens):
-        return lens.to(device=device, dtype=torch.int32)
+        return ops.h2d(lens, device, torch.int32)
     if all(int(l) >= T for l in lens):
         return None
-    return torch.tensor([int(l) for l in lens], dtype=torch.int32, device=device)
+    return ops.h2d([int(l) for l in lens], device, torch.int32)
 
 
 def run_stack(rec, x, lens_dev, depth, residual, h_prev=None, gc0=None, w_ih0=None):
@@ -142,7 +141,7 @@ def packed_mean(out, lens, T):
     """model_utils.packed_mean: sum over the (zero padded) time axis / length."""
     if lens is None:
         return out.sum(dim=0) / float(T)
-    l = torch.as_tensor(lens, dtype=torch.float32, device=out.device).view(-1, 1)
+    l = ops.h2d([float(v) for v in lens] if not torch.is_tensor(lens) else lens, out.device, torch.float32).view(-1, 1)
     return out.sum(dim=0) / l
 
 

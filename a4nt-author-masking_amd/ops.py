@@ -549,6 +549,23 @@ class _LstmLayer(Function):
 HIDDEN_SIZES = (64, 128, 256, 512, 1024)      # instantiations of the persistent sweeps (lstm.hip)
 
 
+def h2d(t, device, dtype=None):
+    """Host tensor (or list / scalar) -> device without stopping the host: torch's plain .to(device) from pageable
+    memory ends in a stream synchronisation, which drains the GPU queue the host has built up; a pinned staging copy
+    + non_blocking is an asynchronous DMA (the pinned block is kept by torch's host allocator until the copy's event
+    has passed).  Tensors already on `device` pass through."""
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t, dtype=dtype)
+    elif dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    device = torch.device(device)
+    if t.device == device or device.type != 'cuda':
+        return t.to(device)
+    if t.device.type == 'cpu' and not t.is_pinned():
+        t = t.pin_memory()
+    return t.to(device, non_blocking=True)
+
+
 def attach_host_lens(lens_dev, lens_host):
     """Remember the host copy of a device length vector that has already been read back (one read-back per
     generation, gen_decode._GenDecode.forward); host_lens() hands it to later consumers."""

@@ -193,13 +193,54 @@ __global__ __launch_bounds__(1024) void gumbel_bwd_kernel(int V, const float* ds
     for (int v = v0 + tid; v < v1; v += NT) o[v] = coef * (expf((yy[v] - m2) * inv_tau) * inv) * (d[v] - dot);
 }
 
+// The same for rows that fit the registers of one 1024-thread workgroup (V <= 1024 * NV): one read of ds and y, every
+// load of the row in flight at once, the probabilities kept for the output pass (no second read, no second exp).
+template <int NV>
+__global__ __launch_bounds__(1024) void gumbel_bwd_reg_kernel(int V, const float* ds, int ldd, const float* y, int ldy,
+                                                             const float* stats, float coef, float inv_tau, float* out,
+                                                             int ldo) {
+    __shared__ float red[ROWS_MAXW];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* d = ds + (long long)b * ldd;
+    const float* yy = y + (long long)b * ldy;
+    float* o = out + (long long)b * ldo;
+    float dv[NV], yv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + 1024 * i;
+        dv[i] = v < V ? d[v] : 0.f;
+        yv[i] = v < V ? yy[v] : -INFINITY;
+    }
+    const float m2 = stats[2 * b], inv = 1.0f / stats[2 * b + 1];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        yv[i] = expf((yv[i] - m2) * inv_tau) * inv;          // exp(-inf) = 0 past the end of the row
+        dot += yv[i] * dv[i];
+    }
+    dot = block_sum(dot, red);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + 1024 * i;
+        if (v < V) o[v] = coef * yv[i] * (dv[i] - dot);
+    }
+}
+
 extern "C" int a4nt_gumbel_bwd(int B, int V, const float* ds, int ldd, const float* y, int ldy, const float* stats,
                                float coef, float inv_tau, float* out, int ldo, void* stream) {
     if (B <= 0) return A4NT_OK;
     if (V <= 0 || !ds || !y || !stats || !out) { a4nt_set_error("a4nt_gumbel_bwd: bad arguments"); return A4NT_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    if (V > 2048 && V <= 1024 * 16) {
+        if (V <= 1024 * 10)
+            hipLaunchKernelGGL((gumbel_bwd_reg_kernel<10>), dim3(B), dim3(1024), 0, s, V, ds, ldd, y, ldy, stats, coef, inv_tau, out, ldo);
+        else
+            hipLaunchKernelGGL((gumbel_bwd_reg_kernel<16>), dim3(B), dim3(1024), 0, s, V, ds, ldd, y, ldy, stats, coef, inv_tau, out, ldo);
+        return a4nt_check_launch("gumbel_bwd");
+    }
     // in place: one workgroup per row (another workgroup of the row would still be reading what this one overwrites)
     const int q = (out != ds && V >= 4096 && B * 4 <= 2048) ? 4 : 1;
-    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(B, q), dim3(V >= 4096 ? 1024 : 256), 0, (hipStream_t)stream, V, ds, ldd, y, ldy,
+    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(B, q), dim3(V >= 4096 ? 1024 : 256), 0, s, V, ds, ldd, y, ldy,
                        stats, coef, inv_tau, out, ldo);
     return a4nt_check_launch("gumbel_bwd");
 }

@@ -112,8 +112,15 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
     // on it), and each XCD has its own 4 MB L2: XCD x takes a contiguous eighth of a banded tile order (bands of 8
     // tile columns, row-major inside a band), so the ~96 tiles an XCD runs at a time share about 12 A row panels and
     // 8 B column panels (5 MB at K = 512) instead of 48 + 2 spread over the whole matrix.
-    int tile = blockIdx.x;
-    {
+    int tile = blockIdx.x, zz = blockIdx.z;
+    if (gridDim.z > 1 && (gridDim.z & 7) == 0 && gridDim.x <= 32) {
+        // few tiles, K split 8- or 16-fold (the per-step decode products: 128 rows against a [512 x 10001] weight):
+        // every tile of a K slab on ONE XCD, so that the slab's part of the weight (1/8 or 1/16 of it) is fetched
+        // into that XCD's L2 once -- by tiles, each XCD would pull its column panels over the whole K, 2.4x the bytes
+        const int L = blockIdx.z * gridDim.x + blockIdx.x, x = L & 7, q = L >> 3;
+        zz = x + 8 * (q / (int)gridDim.x);
+        tile = q % (int)gridDim.x;
+    } else {
         const int nt = gridDim.x, x = tile & 7, i = tile >> 3;
         tile = x * (nt >> 3) + min(x, nt & 7) + i;
     }
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
         tn = 8 * band + idx % wb;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int wg_kbeg = blockIdx.z * g.kchunk;
+    const int wg_kbeg = zz * g.kchunk;
     const int wg_kend = min(g.K, wg_kbeg + g.kchunk);
     // k-groups: ceil(tiles/KG) K tiles each
     const int wg_len = max(0, wg_kend - wg_kbeg);
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
     const int kend = min(wg_kend, kbeg + tg * BK);
     const int nk = min(tg, wg_len / BK);               // group 0 has the most full tiles
     const bool partial = (wg_len % BK) != 0;
-    float* C = g.C + (long long)blockIdx.z * g.slab;
+    float* C = g.C + (long long)zz * g.slab;
 
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
     }
 
     // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const bool add_bias = (g.bias != nullptr) && (blockIdx.z == 0);
+    const bool add_bias = (g.bias != nullptr) && (zz == 0);
     float bcol[WN];
 #pragma unroll
     for (int j = 0; j < WN; ++j) {

@@ -148,6 +148,30 @@ def test_sgemm_splitk(ops):
     assert_close(ops.gemm_auto(A.cuda(), B.cuda(), transB=True), ref.float(), 2e-6, 'gemm_auto')
 
 
+@pytest.mark.parametrize('V', [50, 3000, 10001, 12000, 30001])
+@pytest.mark.parametrize('inplace', [False, True])
+def test_gumbel_bwd_rows(ops, V, inplace):
+    """dlogits = coef * p * (ds - <p, ds>), p = exp((z - max)/tau) / sum: the small-row kernel, the register-resident
+    one (2048 < V <= 16384) and the several-workgroups-per-row one, in place and into a separate buffer."""
+    B, tau, coef = 37, 0.5, 6.0
+    z = _rand(B, V, seed=V, scale=2.0)
+    ds = _rand(B, V, seed=V + 1)
+    zd = z.double()
+    m = zd.max(dim=1, keepdim=True).values
+    e = ((zd - m) / tau).exp()
+    ssum = e.sum(dim=1, keepdim=True)
+    p = e / ssum
+    ref = coef * p * (ds.double() - (p * ds.double()).sum(dim=1, keepdim=True))
+    stats = torch.cat([m, ssum], dim=1).float().cuda()
+    dsg = ops.padded_rows(B, V, 'cuda')
+    dsg.copy_(ds)
+    zg = ops.padded_rows(B, V, 'cuda')
+    zg.copy_(z)
+    out = dsg if inplace else ops.padded_rows(B, V, 'cuda')
+    ops.gumbel_bwd_rows(dsg, zg, stats, coef, 1.0 / tau, out=None if inplace else out)
+    assert_close(out, ref.float(), 2e-6, 'gumbel_bwd V=%d' % V)
+
+
 def test_colsum_embed(ops):
     A = _rand(1000, 333, seed=8)
     assert_close(ops.colsum(A.cuda()), A.double().sum(0).float(), 2e-6, 'colsum')

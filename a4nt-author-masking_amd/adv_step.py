@@ -196,6 +196,9 @@ class GradAllReducer(object):
         self.group = group
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.on else 1
+        # gloo (the CPU stand-in for RCCL in the tests) gets host tensors: its own staging of device tensors has been
+        # seen to stall when the GPU is busy (two ranks sharing one card), and it is not what this class is testing
+        self.host_staged = self.on and dist.get_backend(group) == 'gloo'
         self.params = [p for p in params]
         self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
         if overlap is None:
@@ -229,7 +232,7 @@ class GradAllReducer(object):
         """After the first armed backward: adopt rank 0's ready order on every rank."""
         seen = self._seen + [i for i in range(len(self.params)) if i not in set(self._seen)]
         dev = self.params[0].device
-        order = torch.tensor(seen, dtype=torch.int64, device=dev)
+        order = torch.tensor(seen, dtype=torch.int64, device='cpu' if self.host_staged else dev)
         self.dist.broadcast(order, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                             group=self.group)
         self._order = [int(i) for i in order.tolist()]
@@ -268,8 +271,9 @@ class GradAllReducer(object):
         if not bucket:
             return
         flat = torch.cat([p.grad.reshape(-1) for p in bucket])
-        work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((work, flat, bucket))
+        wire = flat.cpu() if (self.host_staged and flat.is_cuda) else flat
+        work = self.dist.all_reduce(wire, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, flat, wire, bucket))
 
     # -- common ---------------------------------------------------------------------------------
     def launch(self):
@@ -290,8 +294,10 @@ class GradAllReducer(object):
 
     def wait(self):
         """Finish the exchange and write the averaged gradients back."""
-        for work, flat, bucket in self._pending:
+        for work, flat, wire, bucket in self._pending:
             work.wait()
+            if wire is not flat:
+                flat.copy_(wire)
             flat.div_(self.world)
             off = 0
             for p in bucket:
@@ -304,7 +310,12 @@ class GradAllReducer(object):
         """Sum a small tensor over ranks (the err_a1/err_a2 counters that steer the D loop,
         train_adversarial_translator.py:438,745-746, must agree on every rank)."""
         if self.on:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.host_staged and t.is_cuda:
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
     def token_weight(self, n_local):
@@ -312,6 +323,10 @@ class GradAllReducer(object):
         mean over the GLOBAL token count (ragged batches: ranks hold different numbers of valid tokens)."""
         if not self.on:
             return 1.0
+        if self.host_staged:
+            t = torch.tensor(float(n_local))
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            return (float(n_local) * self.world) / float(t)
         t = ops.h2d(float(n_local), self.params[0].device, torch.float32)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return (float(n_local) * self.world) / t          # stays on the device: no host sync

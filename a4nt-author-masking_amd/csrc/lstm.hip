@@ -82,7 +82,17 @@ __device__ __forceinline__ void lstm_fwd_body(const LstmFwdArgs& a, const int bi
     __shared__ int s_ok;
 
     int g, j;
-    decode_bid(bid, a.G, g, j);
+    if (DEC && (a.NW & 7) == 0) {
+        // A single decoder step has no hand-off inside the launch (h_{t-1} was published by the previous launch), so
+        // its placement is free: XCD x (= bid % 8) takes the unit blocks j in [x*NW/8, (x+1)*NW/8) of EVERY row group.
+        // Each XCD then reads one eighth of W_hh per step, and the same eighth at every step, instead of all of it
+        // for its own row group (8 x 4 MB per launch at H = 512: most of the launch was that fetch).
+        const int per = a.NW >> 3, x = bid & 7, q = bid >> 3;
+        j = x * per + q % per;
+        g = q / per;
+    } else {
+        decode_bid(bid, a.G, g, j);
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H = a.H, H4 = 4 * a.H;
     constexpr int nj = NJ;                 // 16-wide k blocks in this wave's K quarter (H = 64*NJ)

@@ -32,10 +32,11 @@ LABELS = [
     (r'conv1d_kernel', 'conv1d'),
     (r'proj_gumbel_kernel', 'proj_gumbel'),
     (r'proj_gumbel_final_kernel', 'proj_gumbel_final'),
-    (r'gumbel_bwd_kernel', 'gumbel_bwd'),
+    (r'gumbel_bwd(_reg)?_kernel', 'gumbel_bwd'),
     (r'nll_rows_kernel', 'nll_rows'),
-    (r'lstm_cell_bwd_kernel', 'lstm_cell_bwd'),
-    (r'slab_reduce_kernel', 'slab_reduce'),
+    (r'lstm_cell_bwd4?_kernel', 'lstm_cell_bwd'),
+    (r'slab_reduce4?_kernel', 'slab_reduce'),
+    (r'colsum_kernel', 'colsum'),
 ]
 
 

@@ -107,3 +107,48 @@ def test_half_batches_add_up(impl, gen):
     impl.check_timeouts()
     for n in whole:
         assert_close(a[n] + b[n], whole[n], 2e-5, 'grad ' + n)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('end_c', [-1, 7])
+def test_native_loops_equal_python_loops(impl, gen, end_c):
+    """The library's C++ step loops (sampler finalisation merged into the next decoder step's prologue, one finalize
+    launch per chunk) against the Python per-step loops (one finalize launch per step): same tokens and lengths, bit
+    for bit; straight-through values, loss and gradients to rounding (the merge adds a row's strips in another
+    order).  With an end token the generation runs in chunks of CHECK_EVERY steps and some rows stop early."""
+    from a4nt_amd import gen_decode
+    x, lens = _ragged(B, 11)
+    auths = torch.zeros(B, dtype=torch.long)
+    n_max = 37
+    res = []
+    if end_c >= 0:
+        with torch.no_grad():
+            gen.decoder_b[end_c] += 1.0        # ~4 % per step: rows end at different steps, a few run to n_max
+    for py in (True, False):
+        gen_decode.PY_LOOPS = py
+        try:
+            gen.zero_grad()
+            gen._noise_step = 0
+            s, gl, co = gen.forward_advers_gen(x, lens, soft_samples=True, temp=0.5, n_max=n_max, end_c=end_c, auths=auths,
+                                               compact=True)
+            emb = gen_decode.sample_embed(s, gen.char_emb.weight)   # [n, B, E]: what a consumer of the samples computes
+            w = torch.linspace(0.5, 1.5, emb.shape[-1], device=emb.device)
+            loss = (emb * w).sum() / emb.shape[1]
+            loss.backward()
+            res.append((s.tok.clone(), gl.clone(), s.val.clone(), loss.detach().clone(),
+                        {k: p.grad.clone() for k, p in gen.named_parameters() if p.grad is not None}))
+        finally:
+            gen_decode.PY_LOOPS = False
+    if end_c >= 0:
+        with torch.no_grad():
+            gen.decoder_b[end_c] -= 1.0
+    impl.check_timeouts()
+    (tok_p, gl_p, val_p, loss_p, g_p), (tok_n, gl_n, val_n, loss_n, g_n) = res
+    assert torch.equal(tok_p, tok_n) and torch.equal(gl_p, gl_n)
+    if end_c >= 0:
+        assert int(gl_n.min()) < n_max, 'no row ended early: the end-token branch was not exercised'
+    assert_close(val_n, val_p, 1e-6, 'straight-through values')
+    assert_close(loss_n, loss_p, 1e-6, 'loss')
+    assert set(g_p) == set(g_n)
+    for k in g_p:
+        assert_close(g_n[k], g_p[k], 2e-5, 'grad ' + k)

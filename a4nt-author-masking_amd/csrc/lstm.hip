@@ -923,25 +923,28 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void lstm_bwd2d2_kernel(LstmB
 // geometry time, not a spin that runs into A4NT_SPIN_LIMIT.
 // a4nt_lstm_set_max_workgroups(256) restores one workgroup per CU for every instantiation (data
 // parallelism: leaves register space for RCCL's kernels).
-static int g_max_wgs = 512;
 #define A4NT_MAX_DEV 16
+static int g_max_wgs[A4NT_MAX_DEV + 1];       // per device (last slot: no current device); 0 = the default, 512
 // [device][mt index 0..2][nj index 0..4]: co-resident workgroups (CUs x occupancy, min over the forward and the
 // backward kernel); 0 = not probed (no device initialised: the static caps alone apply).  [..][1] = pair kernels.
 static int g_resident[A4NT_MAX_DEV][2][3][5];
 static int ilog2(int v) { int r = 0; while ((1 << (r + 1)) <= v) ++r; return r; }
 extern "C" int a4nt_lstm_set_max_workgroups(int n) {
     if (n != 256 && n != 512) { a4nt_set_error("a4nt_lstm_set_max_workgroups: 256 or 512"); return A4NT_ERR_ARG; }
-    g_max_wgs = n;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= A4NT_MAX_DEV) { (void)hipGetLastError(); dev = A4NT_MAX_DEV; }
+    g_max_wgs[dev] = n;                   // a setting of the calling thread's current device
     return A4NT_OK;
 }
 static int budget(int mt, int nj, int pair) {
-    int cap = (mt == 1 && nj < 16) ? g_max_wgs : 256;
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < A4NT_MAX_DEV) {
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < A4NT_MAX_DEV;
+    if (!have_dev) { (void)hipGetLastError(); dev = A4NT_MAX_DEV; }      // no device (CPU-only host): static caps
+    const int max_wgs = g_max_wgs[dev] ? g_max_wgs[dev] : 512;
+    int cap = (mt == 1 && nj < 16) ? max_wgs : 256;
+    if (have_dev) {
         const int res = g_resident[dev][pair][ilog2(mt)][ilog2(nj)];
         if (res > 0 && res < cap) cap = res;
-    } else {
-        (void)hipGetLastError();      // no device (CPU-only host): static caps
     }
     return cap;
 }

@@ -73,7 +73,8 @@ int a4nt_sgemm_skinny(int transB, int M, int N, int K, const float* A, int lda, 
  * found co-resident on the current device. */
 int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out);
 /* 512 (default: two workgroups per CU where the instantiation allows it; needs the GPU to itself) or
- * 256 (one per CU for every instantiation: leaves room for other streams' kernels, e.g. RCCL). */
+ * 256 (one per CU for every instantiation: leaves room for other streams' kernels, e.g. RCCL).  A setting of
+ * the calling thread's current device. */
 int a4nt_lstm_set_max_workgroups(int n);
 /* Co-resident workgroups a4nt_init found for the <mt, H> single-sweep kernels on `device` (0: not probed). */
 int a4nt_lstm_resident_workgroups(int device, int mt, int H);

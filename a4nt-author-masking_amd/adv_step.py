@@ -189,12 +189,13 @@ class GradAllReducer(object):
     property of the graph and therefore the same on every rank.
     With world_size 1 (or no process group) every method is a no-op."""
 
-    def __init__(self, params, bucket_mb=32.0, group=None, overlap=None):
+    def __init__(self, params, bucket_mb=32.0, group=None, overlap=None, force=False):
         import os
         import torch.distributed as dist
         self.dist = dist
         self.group = group
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # force: run the collectives even in a group of one rank (exercises the RCCL path on a single GPU)
+        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or bool(force))
         self.world = dist.get_world_size(group) if self.on else 1
         # gloo (the CPU stand-in for RCCL in the tests) gets host tensors: its own staging of device tensors has been
         # seen to stall when the GPU is busy (two ranks sharing one card), and it is not what this class is testing

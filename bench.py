@@ -224,7 +224,15 @@ def main():
                     help='drive the decoder\'s step loops from Python instead of the library\'s C++ loops (A/B)')
     ap.add_argument('--lstm-workgroups', type=int, default=0, choices=(0, 256, 512),
                     help='persistent LSTM sweep residency (0: 512 on one GPU, 256 beside RCCL kernels when N > 1)')
+    ap.add_argument('--dp-rehearsal', action='store_true',
+                    help='one GPU, but with the data-parallel machinery live: RCCL process group of one rank, gradient '
+                         'buckets all-reduced under backward(), one LSTM workgroup per CU (what every rank of an N > 1 run does)')
     args = ap.parse_args()
+    # stdout carries exactly one line, the result: whatever libraries print on the way (RCCL announces its version on
+    # stdout when a communicator is created) goes to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     wl = set_workload(args.workload)
     if args.batch is None:
         args.batch = B
@@ -236,6 +244,10 @@ def main():
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    elif args.dp_rehearsal:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
     import a4nt_amd as impl
     from a4nt_amd import ops
     if args.no_pack_w:
@@ -246,7 +258,7 @@ def main():
         gen_decode.PY_LOOPS = True
     if args.lstm_workgroups:
         impl.lstm_set_max_workgroups(args.lstm_workgroups)
-    elif world > 1:
+    elif world > 1 or args.dp_rehearsal:
         # leave half of every CU's registers to the RCCL kernels that run beside the persistent LSTM sweeps
         impl.lstm_set_max_workgroups(256)
 
@@ -266,8 +278,9 @@ def main():
         optG, optD = torch.optim.RMSprop(G.parameters(), lr=1e-4, alpha=0.99, eps=1e-8), None
     else:
         optG, optD = None, torch.optim.RMSprop(D.parameters(), lr=1e-3, alpha=0.99, eps=1e-8)
-    reducers = (impl.GradAllReducer(list(G.parameters())) if G is not None else None,
-                impl.GradAllReducer(list(D.parameters())) if D is not None else None)
+    force = bool(args.dp_rehearsal)
+    reducers = (impl.GradAllReducer(list(G.parameters()), force=force) if G is not None else None,
+                impl.GradAllReducer(list(D.parameters()), force=force) if D is not None else None)
     batches = make_batches(impl, 1234 + rank, args.batch, 6, ragged=args.ragged)
     if args.workload == 'cfg1':
         run_step = lambda it, red: clf_step(impl, D, optD, batches, it, args.batch)
@@ -345,8 +358,8 @@ def main():
             line['roofline']['other_kernels'] = others
         if world == 1 and not args.no_cpu_baseline and args.workload == 'adv' and not args.ragged:
             line['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(line))
-    if world > 1:
+        os.write(result_fd, (json.dumps(line) + '\n').encode())
+    if world > 1 or args.dp_rehearsal:
         dist.destroy_process_group()
 
 

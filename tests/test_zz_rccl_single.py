@@ -1,0 +1,78 @@
+"""GPU: the data-parallel step over RCCL (torch.distributed backend "nccl") in a group of ONE rank.
+
+More ranks need more GPUs than the test box has (RCCL refuses two ranks on one device), but a group of one still runs
+the real thing end to end: the process group on RCCL, flat device buckets all-reduced asynchronously on RCCL's stream
+from inside backward(), stream-ordered `work.wait()`, the device-side token weight and the scalar all-reduce — with
+the host never synchronising inside the step.  Averaging over one rank is the identity, so the result must equal the
+plain single-process step bit for bit (embedding gradients, which are atomic scatter-adds, to rounding).  Runs in a child process (the process group is per process)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_zz_dp_gpu import _inputs, _models, _step          # same shapes and inputs as the two-rank gloo test
+
+
+def _child(port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    import a4nt_amd as impl
+    impl.lstm_set_max_workgroups(256)
+    src, tgt, gb, noise = _inputs()
+    res = {}
+    for mode in ('plain', 'rccl'):
+        G, D = _models(impl)
+        reds = (None, None)
+        if mode == 'rccl':
+            reds = (impl.GradAllReducer(list(G.parameters()), bucket_mb=0.01, force=True),
+                    impl.GradAllReducer(list(D.parameters()), bucket_mb=0.01, force=True))
+            assert reds[0].on and not reds[0].host_staged
+        for it in range(2):                                   # second pass: buckets go out under backward()
+            G.zero_grad(); D.zero_grad()
+            out = _step(impl, G, D, src, tgt, gb, [u.clone() for u in noise], reds)
+        if mode == 'rccl':
+            cnt = reds[1].all_reduce_scalars(torch.tensor([3.0, 4.0], device='cuda'))
+            assert cnt.tolist() == [3.0, 4.0]
+        impl.check_timeouts()
+        torch.cuda.synchronize()
+        res[mode] = ({n: p.grad.cpu().numpy() for n, p in G.named_parameters()},
+                     {n: p.grad.cpu().numpy() for n, p in D.named_parameters()}, float(out[1]['grad_norm']),
+                     float(out[1]['cyc_loss']))
+    dist.destroy_process_group()
+    q.put(res)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_rccl_group_of_one_equals_plain_step():
+    import numpy as np
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_child, args=(29900 + (os.getpid() % 90), q))
+    p.start()
+    import queue
+    try:
+        res = q.get(timeout=200)
+    except queue.Empty:
+        p.kill()
+        p.join(timeout=30)
+        raise AssertionError('the RCCL single-rank step produced no result within 200 s (exit code %s)' % p.exitcode)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    (gG, gD, gn, cyc), (rG, rD, rn, rcyc) = res['plain'], res['rccl']
+    assert cyc == rcyc and abs(gn - rn) <= 1e-6 * abs(gn)
+    for a, b in ((gG, rG), (gD, rD)):
+        assert set(a) == set(b)
+        for k in a:
+            if 'emb' in k or 'encoder.weight' in k:
+                # embedding gradients are scatter-added with fp32 atomics: the order of the adds varies run to run
+                assert np.abs(a[k] - b[k]).max() <= 2e-6 * max(np.abs(a[k]).max(), 1e-30), k
+            else:
+                assert np.array_equal(a[k], b[k]), k

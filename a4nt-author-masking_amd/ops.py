@@ -4,6 +4,7 @@ Everything here allocates with torch, passes raw device pointers + the current H
 liba4nt_hip.so and wires the results into torch.autograd.  There is no CPU / eager fallback: a
 tensor that is not a float32 CUDA tensor is an error.
 """
+import contextlib
 import ctypes
 import threading
 
@@ -328,8 +329,32 @@ def lstm_rows_fit(B, H):
 def lstm_set_max_workgroups(n):
     """256: one persistent-sweep workgroup per CU (leaves register space for kernels of other streams,
     e.g. RCCL under data parallelism); 512 (default): two per CU where the geometry allows it."""
+    global _MAX_WGS
     check(_lib.load().a4nt_lstm_set_max_workgroups(int(n)), 'a4nt_lstm_set_max_workgroups')
+    _MAX_WGS = int(n)
     _ws.clear()                 # geometry changed: workspaces are re-made on next use
+
+
+_MAX_WGS = 512
+# Budget of the BACKWARD sweeps alone (None: the same as the forward sweeps').  Data parallelism: the gradient
+# all-reduces run under the backward passes, so those sweeps leave room for RCCL's kernels (256), while the forward
+# sweeps -- no collective is in flight then: every exchange is waited for before the optimizer step -- keep two
+# workgroups per CU.
+BWD_MAX_WGS = None
+
+
+@contextlib.contextmanager
+def _bwd_budget():
+    n = BWD_MAX_WGS
+    if n is None or int(n) == _MAX_WGS:
+        yield
+        return
+    lib = _lib.load()
+    check(lib.a4nt_lstm_set_max_workgroups(int(n)), 'a4nt_lstm_set_max_workgroups')
+    try:
+        yield
+    finally:
+        check(lib.a4nt_lstm_set_max_workgroups(_MAX_WGS), 'a4nt_lstm_set_max_workgroups')
 
 
 def check_timeouts():
@@ -370,13 +395,14 @@ def lstm_seq_bwd(w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0):
     T, B, H4 = gates.shape
     H = H4 // 4
     dev = gates.device
-    xch, sync, _ = _lstm_ws(dev, B, H, True)
     dgates = torch.empty_like(gates)
     dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
     dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
-    with _Timed('lstm_seq_bwd', 8.0 * T * B * H * H):
-        check(lib.a4nt_lstm_seq_bwd(T, B, H, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN),
-                                    _p(dcN), _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync), _s()), 'a4nt_lstm_seq_bwd')
+    with _bwd_budget():
+        xch, sync, _ = _lstm_ws(dev, B, H, True)
+        with _Timed('lstm_seq_bwd', 8.0 * T * B * H * H):
+            check(lib.a4nt_lstm_seq_bwd(T, B, H, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN),
+                                        _p(dcN), _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync), _s()), 'a4nt_lstm_seq_bwd')
     return dgates, dh0, dc0
 
 
@@ -438,26 +464,31 @@ def lstm_seq_fwd_pair(reqs, save=True):
 
 def lstm_seq_bwd_pair(reqs):
     """Two backward sweeps in one launch.  reqs: two tuples (w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0)
-    as for lstm_seq_bwd.  Returns two (dgates, dh0, dc0)."""
+    as for lstm_seq_bwd.  Returns two (dgates, dh0, dc0).  Under a backward budget (BWD_MAX_WGS) that does not hold
+    the pair the two sweeps run one after the other."""
     lib = _lib.load()
     H = reqs[0][1].shape[2] // 4
     dev = reqs[0][1].device
-    mt = lstm_pair_geometry(reqs[0][1].shape[1], reqs[1][1].shape[1], H)[0]
-    probs, outs = [], []
-    flops = 0.0
-    for slot, (w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0) in enumerate(reqs):
-        T, B, _ = gates.shape
-        xch, sync, _g = _lstm_pair_ws(dev, B, H, mt, True, slot)
-        dgates = torch.empty_like(gates)
-        dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
-        dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
-        probs.append(_lib.LstmBwdProblem(T, B, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN),
-                                         _p(dcN), _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync)))
-        outs.append((dgates, dh0, dc0))
-        flops += 8.0 * T * B * H * H
-    with _Timed('lstm_seq_bwd', flops):
-        check(lib.a4nt_lstm_seq_bwd_pair(H, ctypes.byref(probs[0]), ctypes.byref(probs[1]), _s()), 'a4nt_lstm_seq_bwd_pair')
-    return outs
+    with _bwd_budget():
+        geo = lstm_pair_geometry(reqs[0][1].shape[1], reqs[1][1].shape[1], H)
+        if geo is not None:
+            mt = geo[0]
+            probs, outs = [], []
+            flops = 0.0
+            for slot, (w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0) in enumerate(reqs):
+                T, B, _ = gates.shape
+                xch, sync, _g = _lstm_pair_ws(dev, B, H, mt, True, slot)
+                dgates = torch.empty_like(gates)
+                dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
+                dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
+                probs.append(_lib.LstmBwdProblem(T, B, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN),
+                                                 _p(dcN), _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync)))
+                outs.append((dgates, dh0, dc0))
+                flops += 8.0 * T * B * H * H
+            with _Timed('lstm_seq_bwd', flops):
+                check(lib.a4nt_lstm_seq_bwd_pair(H, ctypes.byref(probs[0]), ctypes.byref(probs[1]), _s()), 'a4nt_lstm_seq_bwd_pair')
+            return outs
+    return [lstm_seq_bwd(*r) for r in reqs]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -259,8 +259,14 @@ def main():
     if args.lstm_workgroups:
         impl.lstm_set_max_workgroups(args.lstm_workgroups)
     elif world > 1 or args.dp_rehearsal:
-        # leave half of every CU's registers to the RCCL kernels that run beside the persistent LSTM sweeps
-        impl.lstm_set_max_workgroups(256)
+        # leave half of every CU's registers to the RCCL kernels that run beside the persistent LSTM sweeps.  On the
+        # fused path every exchange has been waited for before the next forward pass starts (the gradient buckets
+        # travel under the BACKWARD passes only), so the forward sweeps keep two workgroups per CU; with two
+        # generation passes the discriminator's exchange runs under the generator's encoder sweeps: one per CU throughout
+        if args.separate_gen:
+            impl.lstm_set_max_workgroups(256)
+        else:
+            ops.BWD_MAX_WGS = 256
 
     torch.manual_seed(0)
     G = impl.CharTranslator(gen_params(args.batch)) if args.workload != 'cfg1' else None

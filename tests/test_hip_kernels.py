@@ -346,6 +346,35 @@ def test_lstm_paired_mixed_grad(ops):
             assert torch.equal(a, b), mode
 
 
+def test_lstm_backward_budget(ops):
+    """ops.BWD_MAX_WGS = 256: backward sweeps take the one-workgroup-per-CU geometry (what data-parallel ranks use
+    under their gradient all-reduces) while the forward sweeps keep two per CU; same results as the default to
+    rounding (another row tiling of the same arithmetic), single and paired, and the forward geometry is untouched."""
+    H, I, T, B = 512, 32, 4, 256
+    P = _stack_params(I, H, 500)
+    x = _rand(T, B, I, seed=51).cuda().requires_grad_(True)
+    xa, xb = _rand(T, 128, I, seed=52).cuda(), _rand(T, 128, I, seed=53).cuda()
+    up, upa = _rand(T, B, H, seed=54).cuda(), _rand(T, 128, H, seed=55).cuda()
+    res = {}
+    for mode in (None, 256):
+        ops.BWD_MAX_WGS = mode
+        try:
+            for v in list(P.values()) + [x]:
+                v.grad = None
+            assert ops.lstm_geometry(B, H)[0] == 1                   # forward: 16 rows per group, 512 workgroups
+            l0 = _stack_loss(ops, P, x, None, up)
+            la, lb = ops.paired(lambda: _stack_loss(ops, P, xa, None, upa), lambda: _stack_loss(ops, P, xb, None, upa))
+            (l0 + la + 2 * lb).backward()
+            ops.check_timeouts()
+            res[mode] = [l0.detach(), la.detach(), lb.detach(), x.grad.clone()] + [P[k].grad.clone() for k in sorted(P)]
+        finally:
+            ops.BWD_MAX_WGS = None
+    for a, b in zip(res[None][:3], res[256][:3]):
+        assert torch.equal(a, b)                                     # forward passes: the same kernels
+    for a, b in zip(res[None][3:], res[256][3:]):
+        assert_close(b, a, 5e-6, 'backward budget 256 vs default')
+
+
 def test_lstm_paired_uneven_and_errors(ops):
     """One side has three layers, the other one; a side that raises surfaces in the caller."""
     H, I, T, B = 64, 16, 4, 6

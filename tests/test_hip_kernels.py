@@ -148,7 +148,7 @@ def test_sgemm_splitk(ops):
     assert_close(ops.gemm_auto(A.cuda(), B.cuda(), transB=True), ref.float(), 2e-6, 'gemm_auto')
 
 
-@pytest.mark.parametrize('V', [50, 3000, 10001, 12000, 30001])
+@pytest.mark.parametrize('V', [50, 2048, 2049, 3000, 10001, 10240, 10241, 12000, 16384, 16385, 30001])   # incl. the kernel selection edges
 @pytest.mark.parametrize('inplace', [False, True])
 def test_gumbel_bwd_rows(ops, V, inplace):
     """dlogits = coef * p * (ds - <p, ds>), p = exp((z - max)/tau) / sum: the small-row kernel, the register-resident

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(1024) void gumbel_bwd_kernel(int V, const float* ds
     for (int v = v0 + tid; v < v1; v += NT) o[v] = coef * (expf((yy[v] - m2) * inv_tau) * inv) * (d[v] - dot);
 }
 
-// The same for rows that fit the registers of one 1024-thread workgroup (V <= 1024 * NV): one read of ds and y, every
+// The same for rows that fit the registers of one 1024-thread workgroup (V <= 1024 * NV, NV up to 32): one read of ds and y, every
 // load of the row in flight at once, the probabilities kept for the output pass (no second read, no second exp).
 template <int NV>
 __global__ __launch_bounds__(1024) void gumbel_bwd_reg_kernel(int V, const float* ds, int ldd, const float* y, int ldy,
@@ -231,11 +231,13 @@ extern "C" int a4nt_gumbel_bwd(int B, int V, const float* ds, int ldd, const flo
     if (B <= 0) return A4NT_OK;
     if (V <= 0 || !ds || !y || !stats || !out) { a4nt_set_error("a4nt_gumbel_bwd: bad arguments"); return A4NT_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
-    if (V > 2048 && V <= 1024 * 16) {
+    if (V > 2048 && V <= 1024 * 32) {
         if (V <= 1024 * 10)
             hipLaunchKernelGGL((gumbel_bwd_reg_kernel<10>), dim3(B), dim3(1024), 0, s, V, ds, ldd, y, ldy, stats, coef, inv_tau, out, ldo);
-        else
+        else if (V <= 1024 * 16)
             hipLaunchKernelGGL((gumbel_bwd_reg_kernel<16>), dim3(B), dim3(1024), 0, s, V, ds, ldd, y, ldy, stats, coef, inv_tau, out, ldo);
+        else
+            hipLaunchKernelGGL((gumbel_bwd_reg_kernel<32>), dim3(B), dim3(1024), 0, s, V, ds, ldd, y, ldy, stats, coef, inv_tau, out, ldo);
         return a4nt_check_launch("gumbel_bwd");
     }
     // in place: one workgroup per row (another workgroup of the row would still be reading what this one overwrites)

@@ -148,11 +148,11 @@ def test_sgemm_splitk(ops):
     assert_close(ops.gemm_auto(A.cuda(), B.cuda(), transB=True), ref.float(), 2e-6, 'gemm_auto')
 
 
-@pytest.mark.parametrize('V', [50, 2048, 2049, 3000, 10001, 10240, 10241, 12000, 16384, 16385, 30001])   # incl. the kernel selection edges
+@pytest.mark.parametrize('V', [50, 2048, 2049, 3000, 10001, 10240, 10241, 12000, 16384, 16385, 30001, 32768, 32769, 40000])   # incl. the kernel selection edges
 @pytest.mark.parametrize('inplace', [False, True])
 def test_gumbel_bwd_rows(ops, V, inplace):
     """dlogits = coef * p * (ds - <p, ds>), p = exp((z - max)/tau) / sum: the small-row kernel, the register-resident
-    one (2048 < V <= 16384) and the several-workgroups-per-row one, in place and into a separate buffer."""
+    one (2048 < V <= 32768) and the several-workgroups-per-row one, in place and into a separate buffer."""
     B, tau, coef = 37, 0.5, 6.0
     z = _rand(B, V, seed=V, scale=2.0)
     ds = _rand(B, V, seed=V + 1)

@@ -303,17 +303,21 @@ def lstm_geometry(B, H):
 
 
 def _lstm_ws(dev, B, H, backward):
-    key = (dev.index, B, H, backward)
+    """Hand-off buffer + sync block of a sweep.  Keyed on the geometry in force NOW (rows per group, groups): the
+    library derives (mt, G) at launch time from the workgroup budget, which lstm_set_max_workgroups and
+    BWD_MAX_WGS change, and the sync block's size and the place of its timeout word (32*G) follow G."""
+    _lib.init_device(dev.index if dev.index is not None else torch.cuda.current_device())
+    mt, g = lstm_geometry(B, H)
+    key = (dev.index, B, H, backward, mt, g)
     if key not in _ws:
         lib = _lib.load()
-        _lib.init_device(dev.index if dev.index is not None else torch.cuda.current_device())
         nf = lib.a4nt_lstm_xch_floats(B, H, int(backward))
         nw = lib.a4nt_lstm_sync_words(B, H)
         if nf < 0 or nw < 0:
             check(1, 'a4nt_lstm workspace')
+        assert nw == 32 * g + 32
         xch = torch.zeros(nf, device=dev, dtype=torch.float32)
         sync = torch.zeros(nw, device=dev, dtype=torch.int32)
-        _, g = lstm_geometry(B, H)
         _ws[key] = (xch, sync, g)
         _sync_blocks.append((sync, g))
     return _ws[key]
@@ -329,13 +333,15 @@ def lstm_rows_fit(B, H):
 def lstm_set_max_workgroups(n):
     """256: one persistent-sweep workgroup per CU (leaves register space for kernels of other streams,
     e.g. RCCL under data parallelism); 512 (default): two per CU where the geometry allows it."""
-    global _MAX_WGS
     check(_lib.load().a4nt_lstm_set_max_workgroups(int(n)), 'a4nt_lstm_set_max_workgroups')
-    _MAX_WGS = int(n)
-    _ws.clear()                 # geometry changed: workspaces are re-made on next use
+    _MAX_WGS[_cur_dev()] = int(n)      # the library keeps this setting per device (the calling thread's current one)
 
 
-_MAX_WGS = 512
+def _cur_dev():
+    return torch.cuda.current_device() if torch.cuda.is_available() else -1
+
+
+_MAX_WGS = {}      # device index -> budget set through lstm_set_max_workgroups (absent: the library's default, 512)
 # Budget of the BACKWARD sweeps alone (None: the same as the forward sweeps').  Data parallelism: the gradient
 # all-reduces run under the backward passes, so those sweeps leave room for RCCL's kernels (256), while the forward
 # sweeps -- no collective is in flight then: every exchange is waited for before the optimizer step -- keep two
@@ -345,8 +351,13 @@ BWD_MAX_WGS = None
 
 @contextlib.contextmanager
 def _bwd_budget():
+    """Backward sweeps under BWD_MAX_WGS: the budget of the device this thread runs on is switched for the duration
+    of the launches and restored to THAT device's own setting.  One host thread per device at a time (the library's
+    budget is a per-device global: two threads launching sweeps on one device while one of them is inside this
+    context would see each other's budget)."""
     n = BWD_MAX_WGS
-    if n is None or int(n) == _MAX_WGS:
+    mine = _MAX_WGS.get(_cur_dev(), 512)
+    if n is None or int(n) == mine:
         yield
         return
     lib = _lib.load()
@@ -354,7 +365,7 @@ def _bwd_budget():
     try:
         yield
     finally:
-        check(lib.a4nt_lstm_set_max_workgroups(_MAX_WGS), 'a4nt_lstm_set_max_workgroups')
+        check(lib.a4nt_lstm_set_max_workgroups(mine), 'a4nt_lstm_set_max_workgroups')
 
 
 def check_timeouts():

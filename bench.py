@@ -10,7 +10,8 @@ Workload: translator enc/dec 1x512, CharLstm discriminator 2x512,
 T = 100, B = 128 per GPU, all lens = T, end_c = -1 (every generation runs T steps), synthetic ids,
 random-init weights (torch.manual_seed(0)), dropout at the reference CLI defaults, fp32.
 
-Launch: `python bench.py --gpus 1` or
+Launch: `python bench.py --gpus N` (N > 1 and no WORLD_SIZE in the environment: this process starts N ranks
+itself through `torch.distributed.run`, before anything touches the GPU, and exits with their return code) or
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (one rank per GPU, RCCL).
 Prints ONE JSON line on rank 0.
 """
@@ -158,6 +159,35 @@ def _latest_profile(stem):
     return files[-1] if files else None
 
 
+_KERNEL_LABELS = (                       # rocprofv3 kernel name prefix -> ops._Timed label
+    ('void sgemm_kernel<true, false, 2, 2,', 'sgemm_tn_128'), ('void sgemm_kernel<false, true, 2, 2,', 'sgemm_nt_128'),
+    ('void sgemm_kernel<false, false, 2, 2,', 'sgemm_nn_128'), ('void sgemm_kernel<false, true, 1, 1,', 'sgemm_nt_64'),
+    ('void proj_gumbel_kernel', 'proj_gumbel'), ('void lstm_fwd', 'lstm_seq_fwd'), ('void lstm_bwd', 'lstm_seq_bwd'))
+
+
+def dominant_kernel(workload='adv'):
+    """(label, source file) of the kernel with the largest share of the step in the latest committed rocprofv3
+    summary of this workload (profiles/rNN_bench_kernel_stats*.csv for the metric's workload,
+    profiles/rNN_<workload>_kernel_stats*.csv otherwise); None when there is no summary or its top kernel is not
+    one the event timer knows."""
+    import csv
+    import glob
+    stem = 'bench' if workload == 'adv' else workload
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s_kernel_stats*.csv' % stem)),
+                   key=lambda f: (os.path.basename(f)[:3], len(f), f))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        rows = list(csv.DictReader(f))
+    if not rows:
+        return None
+    top = max(rows, key=lambda r: float(r['Percentage']))
+    for prefix, label in _KERNEL_LABELS:
+        if top['Name'].startswith(prefix):
+            return label, os.path.relpath(files[-1], ROOT)
+    return None
+
+
 def pmc_traffic(label):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and
@@ -201,6 +231,41 @@ def _synth(g, batch):
     return inps, targs, [T] * batch
 
 
+def self_launch_cmd(n_gpus, argv, port=None):
+    """Command line that runs this script as `n_gpus` ranks of one node (one process per GPU, rendezvous on
+    127.0.0.1: the container's hostname may not resolve).  `argv` = this process's own arguments, passed through."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(int(n_gpus)),
+            '--master-addr', '127.0.0.1', '--master-port', str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(args, argv, environ=None, device_count=None, run=None):
+    """`--gpus N` with N > 1 outside a torch.distributed launch: start the N ranks as fresh child processes and
+    return their exit code (None: nothing to do, this process is the single rank or already one of N).  Runs
+    before any HIP call of this process -- torch.cuda.device_count() does not initialise the GPU -- and never
+    replaces the running program: the children are started with subprocess and this process only waits."""
+    environ = os.environ if environ is None else environ
+    if 'WORLD_SIZE' in environ:
+        world = int(environ['WORLD_SIZE'])
+        if world != args.gpus:
+            raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+        return None
+    if args.gpus <= 1:
+        return None
+    have = torch.cuda.device_count() if device_count is None else device_count
+    if args.gpus > have:
+        raise SystemExit('bench.py: --gpus %d asked for, %d GPU(s) visible on this node' % (args.gpus, have))
+    import subprocess
+    cmd = self_launch_cmd(args.gpus, argv)
+    if run is None:
+        run = lambda c: subprocess.run(c).returncode
+    return run(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -213,9 +278,9 @@ def main():
     ap.add_argument('--separate-gen', action='store_true',
                     help='generate for the D update and for the G update in two passes of B rows (the reference\'s '
                          'loop structure) instead of one pass of 2B rows')
-    ap.add_argument('--roofline-kernel', default='sgemm_nt_128',
+    ap.add_argument('--roofline-kernel', default=None,
                     help='kernel timed with HIP events inside the timed region (default: the kernel with the '
-                         'largest share of the step in profiles/: sgemm_kernel<false,true,2,2,2>)')
+                         'largest share of the step in the latest committed rocprofv3 summary under profiles/)')
     ap.add_argument('--timed-launches', type=int, default=1024,
                     help='HIP event pairs made before the timed region for the roofline kernel (launches beyond go untimed)')
     ap.add_argument('--no-extra-rooflines', action='store_true')
@@ -228,12 +293,19 @@ def main():
                     help='one GPU, but with the data-parallel machinery live: RCCL process group of one rank, gradient '
                          'buckets all-reduced under backward(), one LSTM workgroup per CU (what every rank of an N > 1 run does)')
     args = ap.parse_args()
+    rc = maybe_self_launch(args, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     # stdout carries exactly one line, the result: whatever libraries print on the way (RCCL announces its version on
     # stdout when a communicator is created) goes to stderr instead
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
     wl = set_workload(args.workload)
+    roofline_source = 'command line'
+    if args.roofline_kernel is None:
+        dom = dominant_kernel(args.workload) or dominant_kernel('adv')
+        args.roofline_kernel, roofline_source = dom if dom else ('sgemm_nt_128', 'default (no summary committed)')
     if args.batch is None:
         args.batch = B
 
@@ -320,6 +392,11 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # how many ranks the collective library really joined (1 without a process group)
+    seen = torch.ones(1, device='cuda')
+    if world > 1 or args.dp_rehearsal:
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    ranks_seen = int(seen.item())
     loss_ok = bool(torch.isfinite(rd['loss']).item() and torch.isfinite(rg['loss']).item())
 
     def summarise(tm):
@@ -355,7 +432,9 @@ def main():
                            wl['text'], V + 1, E, T, args.batch,
                            'speech-shaped ragged lens' if args.ragged else 'all lens=T'),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'losses_finite': loss_ok},
-            'roofline': dict({'bound': 'mfma', 'traffic': pmc_traffic(timer['name'])}, **main_rl),
+            'ranks_seen': ranks_seen,
+            'roofline': dict({'bound': 'mfma', 'traffic': pmc_traffic(timer['name']),
+                              'kernel_chosen_from': roofline_source}, **main_rl),
         }
         util = lstm_mfma_util()
         if util is not None and args.workload in ('adv', 'cfg5'):

@@ -12,7 +12,8 @@ while deciding those tokens, so the claim can be read against the fp32 tolerance
          (train_translator.py:93-125), and the fused projection+NLL entry on the same batch
   cfg 3  full adversarial step (D update + G update with 'ml' reconstruction), H=E=512, V=10001, T=100, B=16,
          ragged and all-T lengths (train_adversarial_translator.py:433-735); greedy decode of the same model
-  cfg 5  stress shape: translator 1x1024, V=30001, T=200, CharCNN discriminator, B=8
+  cfg 5  stress shape: translator 1x1024, V=30001, T=200, CharCNN discriminator, B=8; and the same 8 sentences as
+         rows 0-7 of a B=256 batch (the benchmark's geometry: 64 rows per sweep group) against the 8-row run
 The oracle itself is pinned to the reference by tests/test_oracle_golden.py.
 """
 import os
@@ -249,3 +250,76 @@ def test_cfg3_adversarial_step_full_dims(env, lens_kind):
 def test_cfg5_shape_adversarial_step(env):
     """cfg 5's shape (translator 1x1024, V=30001, T=200, CharCNN discriminator) with 8 sentences."""
     _adv_step_case(env, 30000, 512, 1024, 200, 8, 'cnn', 'ragged', 61, sharpen=30.0)
+
+
+def _cfg5_inputs(impl, B=8, seed=61):
+    """The sentences and the Gumbel uniforms of test_cfg5_shape_adversarial_step's generator update (same generator
+    stream as _adv_step_case: three batches, then 2T noise tensors of which the G update uses the last T)."""
+    V, T = 30000, 200
+    g = torch.Generator().manual_seed(seed + 2)
+    mk = lambda a: (lambda b: (b[0], b[1], torch.full((B,), a, dtype=torch.long), b[2]))(
+        impl.synthetic_batch(g, T, B, V, _ragged(g, B, T, lo=T // 4)))
+    src, tgt, gb = mk(0), mk(1), mk(0)
+    noise = [torch.rand(B, V + 1, generator=g) for _ in range(2 * T)]
+    return gb, noise[T:]
+
+
+@pytest.mark.timeout(900)
+def test_cfg5_production_geometry_rows(env):
+    """cfg 5 at its BENCHMARK geometry.  H=1024 with B=256 runs the 64-rows-per-group sweeps (lstm_fwd_kernel<4,16>
+    and the 64-row backward) where the oracle-pinned 8-sentence case above runs the 16-row kernels.  Rows are
+    independent, so: the 8 oracle-pinned sentences (same weights, ids, lengths and Gumbel uniforms as
+    test_cfg5_shape_adversarial_step's generator update) are rows 0-7 of a 256-row batch whose other rows are
+    random sentences; a loss over rows 0-7 only (GAN loss of the CharCNN discriminator on the sampled sentences +
+    teacher-forced CE of the translator) must give the same sampled tokens (exact), the same per-row logits / CE
+    (1e-5) and the same parameter gradients (1e-5 of each gradient's max: the other rows contribute exact zeros)
+    as the 8-row run.  Both runs are the HIP path; the 8-row run is what the test above compares with the oracle."""
+    impl, oracle = env
+    V, E, H, T, R, BB = 30000, 512, 1024, 200, 8, 256
+    torch.manual_seed(61)
+    G = impl.CharTranslator(_gen_params(V, E, H, R)).cuda().train()
+    with torch.no_grad():
+        G.decoder_W.mul_(30.0)
+    torch.manual_seed(62)
+    D = impl.CharCNN(_cnn_params(V, E)).cuda().train()
+    (inps, targs, auths, lens), noise = _cfg5_inputs(impl, R)
+    g2 = torch.Generator().manual_seed(991)
+    xi, xt, xl = impl.synthetic_batch(g2, T, BB - R, V, [int(v) for v in torch.randint(T // 4, T + 1, (BB - R,), generator=g2)])
+    big = (torch.cat([inps, xi], 1), torch.cat([targs, xt], 1), torch.cat([auths, torch.zeros(BB - R, dtype=torch.long)]),
+           list(lens) + list(xl))
+    assert impl.ops.lstm_geometry(BB, H) == (4, 4) and impl.ops.lstm_geometry(R, H)[0] == 1
+    res = {}
+    for tag, (bi, bt, ba, bl) in (('rows8', (inps, targs, auths, lens)), ('rows256', big)):
+        B = bi.shape[1]
+        G.zero_grad(); D.zero_grad()
+        U = []
+        for t in range(T):
+            u = torch.rand(B, V + 1, device='cuda', generator=None) if B > R else None
+            if u is None:
+                u = noise[t].cuda()
+            else:
+                u[:R] = noise[t].cuda()
+            U.append(u)
+        G.set_noise(U)
+        out = impl.adv_forward_pass(G, D, bi, bl, end_c=1, backprop_for='all', maxlen=T, auths=ba, cycle_compute=False)
+        logits, toks, gl = out[0], torch.stack(list(out[4])), out[3]
+        loss = 5 * F.binary_cross_entropy_with_logits(logits[:R, 1], torch.ones(R, device='cuda'), reduction='sum')
+        scores, _ = G.forward_mltrain(bi, bl, bi, bl, auths=ba)
+        ce = torch.stack([F.cross_entropy(scores[:bl[r], r], bt[:bl[r], r].cuda(), reduction='sum') for r in range(R)])
+        (loss + ce.sum() / 100.0).backward()
+        impl.check_timeouts()
+        res[tag] = dict(tok=toks[:, :R].cpu().clone(), gl=gl[:R].cpu().clone(), logits=logits[:R].detach().cpu(),
+                        ce=ce.detach().cpu(), gG={k: v.detach().cpu().clone() for k, v in _grads(G).items()},
+                        gD={k: v.detach().cpu().clone() for k, v in _grads(D).items()})
+        del scores, out, U
+        G.set_noise(None)
+        torch.cuda.empty_cache()
+    a, b = res['rows8'], res['rows256']
+    assert torch.equal(a['gl'], b['gl'])
+    assert torch.equal(a['tok'], b['tok']), '%d of %d sampled tokens differ' % (int((a['tok'] != b['tok']).sum()), a['tok'].numel())
+    assert_close(b['logits'], a['logits'], TOL_OUT, 'cfg5 rows 0-7 of 256: D logits')
+    assert_close(b['ce'], a['ce'], TOL_OUT, 'cfg5 rows 0-7 of 256: per-row CE')
+    wG = _assert_grad_dicts(b['gG'], a['gG'], 1e-5, 'cfg5 rows 0-7 of 256: G grads')
+    wD = _assert_grad_dicts(b['gD'], a['gD'], 1e-5, 'cfg5 rows 0-7 of 256: D grads')
+    print('cfg5 B=256 geometry vs the 8-row run: %d tokens exact, logits err %.2e, CE err %.2e, worst G grad err %.2e, '
+          'worst D grad err %.2e' % (a['tok'].numel(), rel_err(b['logits'], a['logits']), rel_err(b['ce'], a['ce']), wG, wD))

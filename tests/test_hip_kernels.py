@@ -219,7 +219,9 @@ def _ref_lstm(x, lens, lstm, h0, c0, up, uph, upc):
                                             (5, 300, 16, 64, True), (4, 40, 32, 1024, True),
                                             (3, 256, 16, 1024, False),
                                             (4, 100, 16, 1024, True), (4, 128, 16, 1024, False),   # one workgroup per CU at H=1024
-                                            (3, 700, 16, 512, True)])     # more rows than one sweep holds: chunked
+                                            (3, 700, 16, 512, True),      # more rows than one sweep holds: chunked
+                                            (200, 256, 16, 1024, True),   # cfg 5's production geometry, full length
+                                            (100, 256, 16, 512, True)])   # cfg 3's 2B-row sweeps, full length
 def test_lstm_layer_fwd_bwd(ops, T, B, I, H, ragged):
     g = torch.Generator().manual_seed(T * 1000 + B)
     lstm = nn.LSTM(I, H, 1)
@@ -240,6 +242,8 @@ def test_lstm_layer_fwd_bwd(ops, T, B, I, H, ragged):
     loss = (out * up.cuda()).sum() + (hN * uph.cuda()).sum() + (cN * upc.cuda()).sum()
     loss.backward()
     ops.check_timeouts()
+    # full-length recurrences (T = 100 / 200, the config dims): gradients to 1e-4
+    TOLG = 1e-4 if T >= 100 else globals()['TOLG']
     assert_close(out, out_r, TOL, 'lstm out')
     assert_close(hN, hN_r, TOL, 'lstm hN')
     assert_close(cN, cN_r, TOL, 'lstm cN')
@@ -373,6 +377,38 @@ def test_lstm_backward_budget(ops):
         assert torch.equal(a, b)                                     # forward passes: the same kernels
     for a, b in zip(res[None][3:], res[256][3:]):
         assert_close(b, a, 5e-6, 'backward budget 256 vs default')
+
+
+def test_lstm_workspace_follows_geometry(ops):
+    """Toggling the backward budget on ONE shape in both directions (256 -> default -> 256 -> default): each launch
+    gets the workspace of the geometry in force at call time (the sync block's size and the place of its timeout
+    word, 32 * groups, follow it), so a switch can neither hide a timeout word nor write past a block."""
+    H, I, T, B = 512, 32, 3, 256
+    P = _stack_params(I, H, 510)
+    x = _rand(T, B, I, seed=61).cuda().requires_grad_(True)
+    up = _rand(T, B, H, seed=62).cuda()
+    first = {}
+    try:
+        for mode in (256, None, 256, None):
+            ops.BWD_MAX_WGS = mode
+            for v in list(P.values()) + [x]:
+                v.grad = None
+            _stack_loss(ops, P, x, None, up).backward()
+            torch.cuda.synchronize()
+            ops.check_timeouts()
+            got = [x.grad.clone()] + [P[k].grad.clone() for k in sorted(P)]
+            if mode in first:
+                for a, b in zip(first[mode], got):
+                    assert torch.equal(a, b)
+            first[mode] = got
+    finally:
+        ops.BWD_MAX_WGS = None
+    dev = torch.cuda.current_device()
+    mine = {k: v for k, v in ops._ws.items() if k[:4] == (dev, B, H, True) and len(k) == 6}
+    assert sorted((k[4], k[5]) for k in mine) == [(1, 16), (2, 8)]
+    for k, (xch, sync, g) in mine.items():
+        assert g == k[5] and sync.numel() == 32 * g + 32
+        assert int(sync[32 * g].item()) == 0
 
 
 def test_lstm_paired_uneven_and_errors(ops):

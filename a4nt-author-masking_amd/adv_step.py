@@ -215,6 +215,8 @@ class GradAllReducer(object):
         self._bucket_of = {}
         self._ready = []
         self._next = 0
+        self._flat, self._views = [], {}
+        self._was_none = set()
 
     # -- bucket layout --------------------------------------------------------------------------
     def _make_buckets(self, order):
@@ -229,6 +231,24 @@ class GradAllReducer(object):
             buckets.append(cur)
         return buckets
 
+    def _set_layout(self, order):
+        """Fix the bucket layout: every bucket is ONE persistent flat tensor and every parameter of it owns a fixed
+        slice (`_views`).  Gradients are accumulated straight into those slices (arm() makes them the parameters'
+        `.grad`), so a step neither concatenates a bucket nor copies the averaged values back."""
+        self._order = [int(i) for i in order]
+        self._buckets_fixed = self._make_buckets(self._order)
+        self._bucket_of = {i: b for b, idxs in enumerate(self._buckets_fixed) for i in idxs}
+        self._flat, self._views = [], {}
+        for idxs in self._buckets_fixed:
+            p0 = self.params[idxs[0]]
+            flat = torch.zeros(sum(self.params[i].numel() for i in idxs), device=p0.device, dtype=p0.dtype)
+            off = 0
+            for i in idxs:
+                n = self.params[i].numel()
+                self._views[i] = flat[off:off + n].view(self.params[i].shape)
+                off += n
+            self._flat.append(flat)
+
     def _fix_layout(self):
         """After the first armed backward: adopt rank 0's ready order on every rank."""
         seen = self._seen + [i for i in range(len(self.params)) if i not in set(self._seen)]
@@ -236,9 +256,32 @@ class GradAllReducer(object):
         order = torch.tensor(seen, dtype=torch.int64, device='cpu' if self.host_staged else dev)
         self.dist.broadcast(order, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                             group=self.group)
-        self._order = [int(i) for i in order.tolist()]
-        self._buckets_fixed = self._make_buckets(self._order)
-        self._bucket_of = {i: b for b, idxs in enumerate(self._buckets_fixed) for i in idxs}
+        self._set_layout(order.tolist())
+
+    def _is_view(self, i):
+        g, v = self.params[i].grad, self._views[i]
+        return g is not None and g.data_ptr() == v.data_ptr() and g.shape == v.shape and g.is_contiguous()
+
+    def _adopt(self, b):
+        """Make the gradients of bucket b live in its flat tensor.  A gradient that exists elsewhere (accumulated by
+        an earlier backward, or produced before the layout was known) is copied in once; a parameter without a
+        gradient gets a zeroed slice and is remembered, so that it is handed back as None if this pass does not
+        touch it either (optimizers skip None gradients: a parameter a pass does not use must stay untouched)."""
+        idxs = self._buckets_fixed[b]
+        if all(self.params[i].grad is None for i in idxs):
+            self._flat[b].zero_()
+            for i in idxs:
+                self.params[i].grad = self._views[i]
+                self._was_none.add(i)
+            return
+        for i in idxs:
+            p, v = self.params[i], self._views[i]
+            if p.grad is None:
+                v.zero_()
+                self._was_none.add(i)
+            elif not self._is_view(i):
+                v.copy_(p.grad)
+            p.grad = v
 
     # -- overlapped path ------------------------------------------------------------------------
     def arm(self):
@@ -250,8 +293,11 @@ class GradAllReducer(object):
         self._armed = True
         self._seen = []
         self._next = 0
+        self._was_none = set()
         if self._buckets_fixed is not None:
             self._ready = [0] * len(self._buckets_fixed)
+            for b in range(len(self._buckets_fixed)):
+                self._adopt(b)               # backward() now accumulates in place, into the flat buckets
 
     def _on_grad(self, p):
         if not self._armed:
@@ -264,17 +310,14 @@ class GradAllReducer(object):
         self._ready[b] += 1
         # issue every complete bucket, strictly in index order
         while self._next < len(self._buckets_fixed) and self._ready[self._next] == len(self._buckets_fixed[self._next]):
-            self._issue([self.params[j] for j in self._buckets_fixed[self._next]])
+            self._issue(self._next)
             self._next += 1
 
-    def _issue(self, bucket):
-        bucket = [p for p in bucket if p.grad is not None]
-        if not bucket:
-            return
-        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+    def _issue(self, b):
+        flat = self._flat[b]
         wire = flat.cpu() if (self.host_staged and flat.is_cuda) else flat
         work = self.dist.all_reduce(wire, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((work, flat, wire, bucket))
+        self._pending.append((work, flat, wire))
 
     # -- common ---------------------------------------------------------------------------------
     def launch(self):
@@ -284,27 +327,37 @@ class GradAllReducer(object):
         if self.overlap and self._armed:
             self._armed = False
             if self._buckets_fixed is None:
-                self._fix_layout()
+                self._fix_layout()           # first step: the gradients exist as autograd made them
+                self._seen_set = set(self._seen)
+                self._was_none = set()
+                for b in range(len(self._buckets_fixed)):
+                    self._adopt(b)
                 self._next = 0
             for b in range(self._next, len(self._buckets_fixed)):
-                self._issue([self.params[j] for j in self._buckets_fixed[b]])
+                self._issue(b)
             self._next = len(self._buckets_fixed)
             return
-        for idxs in self._make_buckets(range(len(self.params))):
-            self._issue([self.params[j] for j in idxs])
+        # exchange after backward: parameter order, gradients copied into the flat buckets once
+        if self._buckets_fixed is None:
+            self._set_layout(range(len(self.params)))
+        self._was_none = set()
+        self._seen = [i for i, p in enumerate(self.params) if p.grad is not None]
+        for b in range(len(self._buckets_fixed)):
+            self._adopt(b)
+            self._issue(b)
 
     def wait(self):
-        """Finish the exchange and write the averaged gradients back."""
-        for work, flat, wire, bucket in self._pending:
+        """Finish the exchange: the averaged gradients are in place (the parameters' .grad are slices of the flat
+        buckets)."""
+        for work, flat, wire in self._pending:
             work.wait()
             if wire is not flat:
                 flat.copy_(wire)
             flat.div_(self.world)
-            off = 0
-            for p in bucket:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+        if self._pending:
+            # parameters this pass never produced a gradient for (their slices travelled as zeros on every rank)
+            for i in self._was_none - set(self._seen):
+                self.params[i].grad = None
         self._pending = []
 
     def all_reduce_scalars(self, t):

@@ -56,6 +56,18 @@ __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte
     v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w);
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 16);
 }
+// the same with a wave-uniform part of the offset in an SGPR (no address VGPRs for per-block offsets)
+__device__ __forceinline__ f32x4 ld16_sc1_s(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uniform_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)uniform_off, 16);
+    f32x4 f;
+    f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+    return f;
+}
+__device__ __forceinline__ void st16_sc1_s(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uniform_off, f32x4 f) {
+    u32x4 v;
+    v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)lane_off, (int)uniform_off, 16);
+}
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ unsigned ld_flag(const unsigned* p) {

@@ -659,40 +659,60 @@ __global__ __launch_bounds__(256) void lstm_bwd2_kernel(LstmBwdArgs a, LstmBwdAr
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward sweep, 2-D decomposition (16 rows per group, H = 256 / 512 / 1024)
+// backward sweep, 2-D decomposition with 16*MT rows per group and LDS-staged step inputs
 // ---------------------------------------------------------------------------------------------
 // The NW = H/16 workgroups of a row group form a P x 4 grid: workgroup (i, q) holds the W_hh block
-// [4 gates x units 64i..64i+63][columns q*H/4 .. (q+1)*H/4) (again H/4 weight registers per lane).  Per step it
+// [4 gates x units 64i..64i+63][columns q*H/4 .. (q+1)*H/4) (H/4 weight registers per lane).  Per step and row tile it
 //   * sums, for ITS 64 units, the P partial dh blocks the workgroups (., q*) of that column range published
-//     (wave w: unit tile 4i+w, P contiguous 1 KiB blocks; the sum lands in the lanes that own those
+//     (wave w: unit tile 4i+w, P x MT contiguous 1 KiB blocks; the sum lands in the lanes that own those
 //     (row, unit) pairs -- no LDS round trip),
-//   * runs the cell backward for its 16 rows x 64 units (4 pairs per thread; the 4 workgroups of a unit block do
-//     this redundantly: element-wise work on data that is prefetched a step ahead), dgates -> LDS [16][256],
+//   * runs the cell backward for 16 rows x 64 units (4 pairs per thread; the 4 workgroups of a unit block do this
+//     redundantly: element-wise work on data that is already in LDS), dgates -> LDS [16][256],
 //   * multiplies that tile with its weight block: a partial dh over H/4 columns,
-//   * publishes it: 16 x H/4 floats per step instead of the 16 x H of the 1-D scheme (lstm_bwd_body), where every
-//     workgroup publishes a partial over ALL columns -- at H = 512 a quarter of the write-through bytes, 2 instead
-//     of 8 stores per wave to drain before the signal, and a quarter of the lines leaving L2.
-// Same hand-off protocol and buffers as lstm_bwd_body (block index differs); one arrival counter per group.
-template <int NT>   // NT = H / 256: 16-column tiles per wave
-__device__ __forceinline__ void lstm_bwd2d_body(const LstmBwdArgs& a, const int bid) {
+//   * publishes it: 16 x H/4 floats per step instead of the 16 x H of the 1-D scheme (lstm_bwd_body, still used for
+//     H <= 128), where every workgroup publishes a partial over ALL columns -- at H = 512 a quarter of the
+//     write-through bytes, 2 instead of 8 stores per wave to drain before the signal.
+// Same hand-off protocol as lstm_bwd_body; one arrival counter per group.  Further:
+//   * MT row tiles of 16 rows share the workgroup's weight registers (32 or 64 rows per group: one workgroup per CU
+//     at 256 rows and H = 512; the only geometry that fits 256 rows at H = 1024).  A tile is processed as
+//     cell backward -> dgates tile in LDS -> MFMA with the weight block -> publish, one tile after the other through
+//     ONE LDS tile, so the accumulators are NT fragments whatever MT (the 1-D kernel's 64-row instantiation spilled).
+//   * The saved activations, cell states and upstream dh of a step never pass through registers: every wave
+//     fetches, for its own 16 units x 16 rows and all six arrays, the NEXT step's values straight into LDS
+//     (global_load_lds_dwordx4: 6 instructions per wave and tile) right after the cell backward of the current step
+//     freed that slot, so they travel under the MFMA chain.  No prefetch registers, no compiler-placed wait on them
+//     at the loop's back edge (the register version waited vmcnt(0) there), and the loads are whole 64-byte pieces
+//     instead of dwords.  The slots are private to a wave (it stages what its own lanes consume), so no barrier is
+//     needed between the fetch and the use.
+// LDS-DMA writes lane-linear: lane p's 16 bytes land at chunk p of the slot.  Chunk p holds (row, unit quad) =
+// (8*(p>>5) + 4*((p>>2)&1) + ((p>>3)&3), p&3): with that order the cell backward's reads (lane = unit, rows
+// 4*(lane&3)+j) spread over all 32 banks (row-major chunks would put the four row groups on the same 16 banks).
+template <int NT, int MT>
+__device__ __forceinline__ void lstm_bwdx_body(const LstmBwdArgs& a, const int bid) {
     constexpr int SA = 260;                                            // LDS row stride of the dgates tile
-    __shared__ __attribute__((aligned(16))) float sA[16 * SA];         // [row][gate*64 + unit]
+    __shared__ __attribute__((aligned(16))) float sA[16 * SA];         // [row][gate*64 + unit], one row tile
+    __shared__ __attribute__((aligned(16))) float sIn[MT][4][6][256];  // [tile][wave][i,f,g,o,c_prev,dhs][chunk*4 + e]
+    // H = 1024 with 64 rows per group: 256 weight registers leave no room for all of the per-row recurrent state, so
+    // c_t and d(c) of the thread's 16 (row, unit) pairs live in LDS words of its own ([.][tid]: conflict-free)
+    constexpr bool ST_LDS = (NT * MT >= 16);
+    __shared__ float sSt[ST_LDS ? 2 * MT * 4 : 1][256];
+    __shared__ int s_len[16 * MT];                                     // row lengths of the group (0 past the batch)
     __shared__ int s_ok;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
 
     int g, jw;
     decode_bid(bid, a.G, g, jw);
     const int i_blk = jw >> 2, q = jw & 3;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: SGPR)
     const int H = a.H, H4 = 4 * a.H, P = a.H >> 6, NTILES = a.H >> 4;
     const int u0 = 64 * i_blk;
-    const int r0 = g * 16;
+    const int r0 = g * 16 * MT;
     const int fr = lane & 15, fq = lane >> 4;
     const int ul = 16 * w + (lane >> 2);          // this thread's unit inside the block ...
-    const int rj0 = 4 * (lane & 3);               // ... and its 4 rows rj0..rj0+3
+    const int rj0 = 4 * (lane & 3);               // ... and its 4 rows rj0..rj0+3 of every row tile
     const int col0 = q * (H >> 2) + w * 16 * NT;  // first output column of this wave
 
-    // B operands: wreg[c][kb][e] (lane n = fr, k quad fq), kb = gate*4 + unit sub-block:
-    //   W_hh[gate*H + u0 + 16*ub + 4*fq + e][col0 + 16*c + fr]
     float wreg[NT][16][4];
 #pragma unroll
     for (int c = 0; c < NT; ++c)
@@ -705,208 +725,210 @@ __device__ __forceinline__ void lstm_bwd2d_body(const LstmBwdArgs& a, const int 
     unsigned* ctr = a.sync + 32 * g;
     unsigned* tmo = a.tmo;
     const unsigned blk_bytes = 256 * 4;
-    const long long x_par = (long long)a.G * NTILES * P * 256;         // floats per parity
+    const long long x_par = (long long)a.G * NTILES * P * MT * 256;    // floats per parity
     __amdgpu_buffer_rsrc_t rs = make_rsrc(a.gxch, (unsigned)(2 * x_par * 4));
 
-    float dh_rec[4], dc_next[4];
-    int len_r[4];
+    constexpr int NST = ST_LDS ? 1 : MT;
+    float dh_rec[MT][4], dc_next[NST][4], ct_cur[NST][4];
     int Tg = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rb = r0 + rj0 + j;
-        dh_rec[j] = 0.f; dc_next[j] = 0.f;
-        len_r[j] = (rb < a.B) ? (a.lens ? min(a.lens[rb], a.T) : a.T) : 0;
-    }
-    if (a.lens) {
-        for (int r = 0; r < 16; ++r) {
-            const int rb = r0 + r;
-            if (rb < a.B) Tg = max(Tg, min(a.lens[rb], a.T));
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dh_rec[m][j] = 0.f;
+            if (ST_LDS) sSt[(MT + m) * 4 + j][tid] = 0.f; else dc_next[m][j] = 0.f;
         }
-    } else {
-        Tg = a.T;
+    if (tid < 16 * MT) {
+        const int rb = r0 + tid;
+        s_len[tid] = (rb < a.B) ? (a.lens ? min(a.lens[rb], a.T) : a.T) : 0;
     }
+    __syncthreads();
+    for (int r = 0; r < 16 * MT; ++r) Tg = max(Tg, s_len[r]);
     // dgates of the steps no row of this group ran (each of the four workgroups of a unit block: one gate)
     for (int t = Tg; t < a.T; ++t)
-        for (int idx = tid; idx < 16 * 64; idx += 256) {
+        for (int idx = tid; idx < 16 * MT * 64; idx += 256) {
             const int row = idx >> 6, cc = idx & 63;
             if (r0 + row < a.B) a.dgates[((long long)t * a.B + r0 + row) * H4 + q * H + u0 + cc] = 0.f;
         }
 
-    // Step inputs come through buffer loads: ONE per-thread byte offset per array (row rj0 of the thread, its unit)
-    // plus a wave-uniform offset per (row j, gate) in an SGPR -- no 64-bit address arithmetic, no per-load address
-    // registers; rows past the batch or a step before 0 fall outside the descriptor and read as 0 (never used).
-    struct StepIn { float ig, fg, gg, og, cp, dhs; };
-    StepIn cur[4];
-    float ct_cur[4];
-    const long long g_bytes = (long long)a.T * a.B * H4 * 4, c_bytes = (long long)a.T * a.B * H * 4;
-    __amdgpu_buffer_rsrc_t rg = make_rsrc(a.gates, (unsigned)min(g_bytes, 0xffffffffll));
-    __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cs, (unsigned)min(c_bytes, 0xffffffffll));
-    __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dhs ? a.dhs : a.cs, a.dhs ? (unsigned)min(c_bytes, 0xffffffffll) : 0u);
-    __amdgpu_buffer_rsrc_t r0c = make_rsrc(a.c0 ? a.c0 : a.cs, a.c0 ? (unsigned)((long long)a.B * H * 4) : 0u);
-    const unsigned thr_g = (unsigned)(((r0 + rj0) * H4 + u0 + ul) * 4);      // + t * B * 4H * 4
-    const unsigned thr_c = (unsigned)(((r0 + rj0) * H + u0 + ul) * 4);       // + t * B * H * 4
-    const unsigned step_g = (unsigned)(a.B * H4 * 4), step_c = (unsigned)(a.B * H * 4);
-    auto ldf = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-    };
-    auto load_step = [&](int t) {
-        const unsigned og_ = thr_g + (unsigned)t * step_g;          // t = -1 wraps far outside the descriptor: zeros
-        const unsigned oc_ = thr_c + (unsigned)t * step_c;
+    // ---- step inputs: LDS-DMA ---------------------------------------------------------------------------------
+    // source of this lane's chunk: row prow of the tile, units u0 + 16w + 4*(lane&3) .. +3 (rows past the batch are
+    // clamped to the last row: fetched, never used)
+    const int prow = 8 * (lane >> 5) + 4 * ((lane >> 2) & 1) + ((lane >> 3) & 3);
+    const int pun = u0 + 16 * w + 4 * (lane & 3);
+    int src_row[MT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            cur[j].ig = ldf(rg, og_, (unsigned)((j * H4) * 4));
-            cur[j].fg = ldf(rg, og_, (unsigned)((j * H4 + H) * 4));
-            cur[j].gg = ldf(rg, og_, (unsigned)((j * H4 + 2 * H) * 4));
-            cur[j].og = ldf(rg, og_, (unsigned)((j * H4 + 3 * H) * 4));
-            if (t > 0) cur[j].cp = ldf(rc, oc_ - step_c, (unsigned)(j * H * 4));
-            else cur[j].cp = ldf(r0c, thr_c, (unsigned)(j * H * 4));             // c0 (null: empty descriptor -> 0)
-            cur[j].dhs = ldf(rd, oc_, (unsigned)(j * H * 4));
+    for (int m = 0; m < MT; ++m) src_row[m] = min(r0 + 16 * m + prow, a.B - 1);
+    // where the cell backward finds (row rj0 + j, unit ul) in a slot: chunk 8*(j + 4*(row>>3)) + 4*((row>>2)&1) + quad
+    const int rd0 = 4 * (8 * (4 * ((lane & 3) >> 1)) + 4 * (lane & 1) + (lane >> 4)) + ((lane >> 2) & 3);   // + 32*j
+    if (!a.dhs) {                            // no upstream dh: that array's slots stay zero for the whole sweep
+#pragma unroll
+        for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(&sIn[m][w][5][4 * lane]) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    auto fetch = [&](const int t, const int m) {
+        const long long o = (long long)t * a.B + src_row[m];
+        const float* pg = a.gates + o * H4 + pun;
+        __builtin_amdgcn_global_load_lds((gptr_t)(pg), (lptr_t)&sIn[m][w][0][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pg + H), (lptr_t)&sIn[m][w][1][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pg + 2 * H), (lptr_t)&sIn[m][w][2][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pg + 3 * H), (lptr_t)&sIn[m][w][3][0], 16, 0, 0);
+        if (t > 0) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.cs + (o - a.B) * H + pun), (lptr_t)&sIn[m][w][4][0], 16, 0, 0);
+        } else if (a.c0) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.c0 + (long long)src_row[m] * H + pun), (lptr_t)&sIn[m][w][4][0], 16, 0, 0);
+        } else {
+            *reinterpret_cast<f32x4*>(&sIn[m][w][4][4 * lane]) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.dhs) __builtin_amdgcn_global_load_lds((gptr_t)(a.dhs + o * H + pun), (lptr_t)&sIn[m][w][5][0], 16, 0, 0);
+    };
+    if (Tg > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            fetch(Tg - 1, m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb = min(r0 + 16 * m + rj0 + j, a.B - 1);
+                const float c_last = a.cs[((long long)(Tg - 1) * a.B + rb) * H + u0 + ul];
+                if (ST_LDS) sSt[m * 4 + j][tid] = c_last; else ct_cur[m][j] = c_last;
+            }
+        }
+    }
+
+    auto store_dgates = [&](const int t, const int m) {
+        for (int idx = tid; idx < 16 * 64; idx += 256) {
+            const int row = idx >> 6, cc = idx & 63;
+            if (r0 + 16 * m + row < a.B)
+                a.dgates[((long long)t * a.B + r0 + 16 * m + row) * H4 + q * H + u0 + cc] = sA[row * SA + q * 64 + cc];
         }
     };
-    load_step(Tg - 1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        ct_cur[j] = Tg > 0 ? ldf(rc, thr_c + (unsigned)(Tg - 1) * step_c, (unsigned)(j * H * 4)) : 0.f;
-
-    // L2 warm-up of the step after next: one dword per 128-B line of the 16 rows x {4 gates, c_prev, dhs} x 64 units
-    // this workgroup will read two steps from now (192 lines, one per thread), issued at the top of a step so that
-    // it lands under the cell backward and the MFMA chain.  The loads of a wave return in order, and the loads of
-    // the peers' partial dh -- the hand-off's critical path -- must not queue behind HBM latency: the real inputs
-    // (load_step) are therefore issued AFTER them and find their lines in L2.
-    const int t_row = tid / 12, t_arr = (tid % 12) >> 1, t_half = tid & 1;
-    const unsigned tch_g = (unsigned)(((r0 + t_row) * H4 + (t_arr < 4 ? t_arr : 0) * H + u0 + 32 * t_half) * 4);
-    const unsigned tch_c = (unsigned)(((r0 + t_row) * H + u0 + 32 * t_half) * 4);
-    auto touch = [&](int t) -> float {
-        if (tid >= 192 || t < 0) return 0.f;
-        if (t_arr < 4) return ldf(rg, tch_g + (unsigned)t * step_g, 0u);
-        if (t_arr == 4) return ldf(rc, tch_c + (unsigned)(t - 1) * step_c, 0u);
-        return ldf(rd, tch_c + (unsigned)t * step_c, 0u);
-    };
-    float junk = 0.f, touched = 0.f;
 
     int s = 0;
-    STAMP_DECL
     for (int t = Tg - 1; t >= 0; --t, ++s) {
         const int par = s & 1;
-        STAMP_BEGIN();
-        junk += touched;                      // (consumes the previous step's warm-up load: it landed long ago)
-        touched = touch(t - 2);
-        // (a) cell backward of this thread's 4 (row, unit) pairs -> dgates tile in LDS
+        const bool last = (t == 0 && !a.need_dh0);     // nothing to exchange after the last step's cell backward
+        // this step's inputs were fetched a step ago (or by the prologue); everything this wave has in flight is older
+        // than its last wait except in the first iteration
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rb = r0 + rj0 + j;
-            float dp[4] = {0.f, 0.f, 0.f, 0.f};
-            if (rb < a.B && t < len_r[j]) {
-                const float ig = cur[j].ig, fg = cur[j].fg, gg = cur[j].gg, og = cur[j].og;
-                const float ct = ct_cur[j], cp = cur[j].cp;
-                float dh = dh_rec[j] + cur[j].dhs;
-                float dc = dc_next[j];
-                if (t == len_r[j] - 1) {
-                    if (a.dhN) dh += a.dhN[(long long)rb * H + u0 + ul];
-                    if (a.dcN) dc += a.dcN[(long long)rb * H + u0 + ul];
+        for (int m = 0; m < MT; ++m) {
+            if (m > 0) __syncthreads();               // the previous tile's MFMA and dgates reads of sA are done
+            // (a) cell backward of this thread's 4 (row, unit) pairs of tile m -> dgates tile in LDS
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb = r0 + 16 * m + rj0 + j;
+                const float* in = &sIn[m][w][0][rd0 + 32 * j];
+                const float ig = in[0], fg = in[256], gg = in[512], og = in[768], cp = in[1024], dhs = in[1280];
+                float dp[4] = {0.f, 0.f, 0.f, 0.f};
+                const int len_rj = s_len[16 * m + rj0 + j];          // 0 for rows past the batch
+                if (t < len_rj) {
+                    const float ct = ST_LDS ? sSt[m * 4 + j][tid] : ct_cur[ST_LDS ? 0 : m][j];
+                    float dh = dh_rec[m][j] + dhs;
+                    float dc = ST_LDS ? sSt[(MT + m) * 4 + j][tid] : dc_next[ST_LDS ? 0 : m][j];
+                    if (t == len_rj - 1) {
+                        if (a.dhN) dh += a.dhN[(long long)rb * H + u0 + ul];
+                        if (a.dcN) dc += a.dcN[(long long)rb * H + u0 + ul];
+                    }
+                    const float tc = tanhf_(ct);
+                    dc += dh * og * (1.f - tc * tc);
+                    dp[0] = dc * gg * ig * (1.f - ig);
+                    dp[1] = dc * cp * fg * (1.f - fg);
+                    dp[2] = dc * ig * (1.f - gg * gg);
+                    dp[3] = dh * tc * og * (1.f - og);
+                    if (ST_LDS) sSt[(MT + m) * 4 + j][tid] = dc * fg; else dc_next[ST_LDS ? 0 : m][j] = dc * fg;
                 }
-                const float tc = tanhf_(ct);
-                dc += dh * og * (1.f - tc * tc);
-                dp[0] = dc * gg * ig * (1.f - ig);
-                dp[1] = dc * cp * fg * (1.f - fg);
-                dp[2] = dc * ig * (1.f - gg * gg);
-                dp[3] = dh * tc * og * (1.f - og);
-                dc_next[j] = dc * fg;
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) sA[(rj0 + j) * SA + gt * 64 + ul] = dp[gt];
+                if (ST_LDS) sSt[m * 4 + j][tid] = cp; else ct_cur[ST_LDS ? 0 : m][j] = cp;
             }
+            __syncthreads();
+            // the slot of tile m is free (its reads are behind this wave): fetch the next step's values into it
+            if (t > 0) fetch(t - 1, m);
+            if (!last) {
+                // (b) partial dh_{t-1}[tile m][:, this wave's 16*NT columns] = dgates tile [16 x 256] * weight block
+                f32x4 acc[NT];
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) sA[(rj0 + j) * SA + gt * 64 + ul] = dp[gt];
-            ct_cur[j] = cur[j].cp;
-        }
-        __syncthreads();
-        if (t == 0 && !a.need_dh0) {
-            for (int idx = tid; idx < 16 * 64; idx += 256) {
-                const int row = idx >> 6, cc = idx & 63;
-                if (r0 + row < a.B) a.dgates[((long long)(r0 + row)) * H4 + q * H + u0 + cc] = sA[row * SA + q * 64 + cc];
+                for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 16; ++kb) {
+                    const f32x4 af = *reinterpret_cast<const f32x4*>(&sA[fr * SA + (kb >> 2) * 64 + 16 * (kb & 3) + 4 * fq]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int c = 0; c < NT; ++c)
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], wreg[c][kb][e], acc[c], 0, 0, 0);
+                }
+                // publish: block (column tile, producer unit block, row tile), [col][row] fragment order
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    const int ctg = (col0 >> 4) + c;
+                    const unsigned blk = (unsigned)((((par * a.G + g) * NTILES + ctg) * P + i_blk) * MT + m);   // wave-uniform
+                    st16_sc1_s(rs, (unsigned)((fr * 16 + 4 * fq) * 4), blk * blk_bytes, acc[c]);
+                }
             }
-            break;
+            // dgates_t of tile m for the time-batched weight-gradient GEMMs (the four workgroups that share the unit
+            // block write one gate each).  Nobody waits for it inside this launch: the last tile's goes out behind the
+            // signal, so that the drain in front of the signal does not wait for these stores
+            if (m + 1 < MT || last) store_dgates(t, m);
         }
-        STAMP(0);
-        // (b) partial dh_{t-1}[:, this wave's 16*NT columns] = dgates tile [16 x 256] * weight block
-        f32x4 acc[NT];
-#pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(&sA[fr * SA + (kb >> 2) * 64 + 16 * (kb & 3) + 4 * fq]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int c = 0; c < NT; ++c)
-                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], wreg[c][kb][e], acc[c], 0, 0, 0);
-        }
-        // publish: block (column tile, producer unit block), [col][row] fragment order, one 1 KiB store per tile
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            const int ctg = (col0 >> 4) + c;
-            const long long blk = (((long long)par * a.G + g) * NTILES + ctg) * P + i_blk;
-            st16_sc1(rs, (unsigned)(blk * blk_bytes + (fr * 16 + 4 * fq) * 4), acc[c]);
-        }
-        STAMP(1);
+        if (last) break;
         drain_vmem();
         __syncthreads();
         if (tid == 0) add_flag(ctr, 1u);
-        STAMP(2);
-        // dgates_t for the time-batched weight-gradient GEMMs (nobody waits for it inside this launch): the four
-        // workgroups that share the unit block write one gate each
-        for (int idx = tid; idx < 16 * 64; idx += 256) {
-            const int row = idx >> 6, cc = idx & 63;
-            if (r0 + row < a.B) a.dgates[((long long)t * a.B + r0 + row) * H4 + q * H + u0 + cc] = sA[row * SA + q * 64 + cc];
-        }
-        STAMP(3);
+        store_dgates(t, MT - 1);
         if (tid == 0) s_ok = wait_ge(ctr, (unsigned)(a.NW * (s + 1)), tmo) ? 1 : 0;
         __syncthreads();
         if (!s_ok) break;
-        STAMP(4);
-        // (c) dh_{t-1} of this wave's unit tile: sum of the P producers' blocks (contiguous), in producer order
-        f32x4 ps = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (c) dh_{t-1} of this wave's unit tile, per row tile: sum of the P producers' blocks, in producer order; the
+        // loads of the next row tile are issued before the sums of this one
         {
-            const long long base = (((long long)par * a.G + g) * NTILES + (u0 >> 4) + w) * P;
-            if (P == 4 * NT) {                   // (always: P = H/64 = 4*NT; spelled out so that the loads are all issued first)
-                f32x4 v[4 * NT];
+            constexpr int PP = 4 * NT;               // = P
+            constexpr int DB = (NT < 4) ? 2 : 1;           // H = 1024: one set of 16 blocks (64 registers) in flight
+            f32x4 v[DB][PP];
+            auto ldp = [&](const int m, f32x4 (&d)[PP]) {
 #pragma unroll
-                for (int p = 0; p < 4 * NT; ++p) v[p] = ld16_sc1(rs, (unsigned)((base + p) * blk_bytes + lane * 16));
-                // the next step's inputs, queued BEHIND the partial loads (warm in L2 since the step before last)
-                load_step(t - 1);
+                for (int p = 0; p < PP; ++p) {
+                    const unsigned blk = (unsigned)((((par * a.G + g) * NTILES + (u0 >> 4) + w) * P + p) * MT + m);   // wave-uniform
+                    d[p] = ld16_sc1_s(rs, (unsigned)(lane * 16), blk * blk_bytes);
+                }
+            };
+            ldp(0, v[0]);
 #pragma unroll
-                for (int p = 0; p < 4 * NT; ++p) { ps.x += v[p].x; ps.y += v[p].y; ps.z += v[p].z; ps.w += v[p].w; }
+            for (int m = 0; m < MT; ++m) {
+                if (DB == 2 && m + 1 < MT) ldp(m + 1, v[(m + 1) & (DB - 1)]);
+                f32x4 ps = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < PP; ++p) { ps.x += v[m & (DB - 1)][p].x; ps.y += v[m & (DB - 1)][p].y; ps.z += v[m & (DB - 1)][p].z; ps.w += v[m & (DB - 1)][p].w; }
+                if (DB == 1 && m + 1 < MT) ldp(m + 1, v[0]);
+                dh_rec[m][0] = ps.x; dh_rec[m][1] = ps.y; dh_rec[m][2] = ps.z; dh_rec[m][3] = ps.w;
             }
         }
-        dh_rec[0] = ps.x; dh_rec[1] = ps.y; dh_rec[2] = ps.z; dh_rec[3] = ps.w;
-        STAMP_WAITV();
-        STAMP(5);
-        // the barrier after the next (a) orders these steps' LDS reads before sA is rewritten: (a) writes sA, and every
-        // wave passed the barrier above only after all MFMA reads of sA (they precede the publish)
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the wave (early exits included)
 
-    STAMP_FLUSH(a.sync, a.G);
-    if (junk == 123.456f && a.T < 0) a.dgates[0] = junk;       // keeps the warm-up loads alive; never true
     if (q == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rb = r0 + rj0 + j;
-            if (rb < a.B) {
-                if (a.dh0) a.dh0[(long long)rb * H + u0 + ul] = dh_rec[j];
-                if (a.dc0) a.dc0[(long long)rb * H + u0 + ul] = dc_next[j];
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb = r0 + 16 * m + rj0 + j;
+                if (rb < a.B) {
+                    if (a.dh0) a.dh0[(long long)rb * H + u0 + ul] = dh_rec[m][j];
+                    if (a.dc0) a.dc0[(long long)rb * H + u0 + ul] = ST_LDS ? sSt[(MT + m) * 4 + j][tid] : dc_next[ST_LDS ? 0 : m][j];
+                }
             }
-        }
     }
 }
 
-// (second launch bound = waves per SIMD the register allocation must leave room for: two row groups per CU
-// up to H = 512, whose hand-off latencies then hide behind each other's MFMA phase)
-template <int NT>
-__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void lstm_bwd2d_kernel(LstmBwdArgs a) { lstm_bwd2d_body<NT>(a, blockIdx.x); }
+// (second launch bound = waves per SIMD the register allocation must leave room for: two row groups per CU for
+// 16-row groups up to H = 512; 32- and 64-row groups and H = 1024 take one workgroup per CU)
+template <int NT, int MT>
+__global__ __launch_bounds__(256, (NT <= 2 && MT == 1) ? 2 : 1) void lstm_bwdx_kernel(LstmBwdArgs a) { lstm_bwdx_body<NT, MT>(a, blockIdx.x); }
 
-template <int NT>
-__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void lstm_bwd2d2_kernel(LstmBwdArgs a, LstmBwdArgs b, int nA) {
+template <int NT, int MT>
+__global__ __launch_bounds__(256, (NT <= 2 && MT == 1) ? 2 : 1) void lstm_bwdx2_kernel(LstmBwdArgs a, LstmBwdArgs b, int nA) {
     const bool first = (int)blockIdx.x < nA;
     const LstmBwdArgs s = first ? a : b;
-    lstm_bwd2d_body<NT>(s, first ? (int)blockIdx.x : (int)blockIdx.x - nA);
+    lstm_bwdx_body<NT, MT>(s, first ? (int)blockIdx.x : (int)blockIdx.x - nA);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -975,6 +997,17 @@ static int pick_mt(int B, int NW, int* G) {
         else hipLaunchKernelGGL((KERNEL<4, 16>), grid, block, 0, s, a);                                           \
     } while (0)
 
+// (the 1-D backward kernel serves H = 64 / 128 only)
+#define A4NT_DISPATCH_LSTM_SMALL(KERNEL, mt, nj, grid, block, s, a)                                             \
+    do {                                                                                                         \
+        if (mt == 1 && nj == 1) hipLaunchKernelGGL((KERNEL<1, 1>), grid, block, 0, s, a);                         \
+        else if (mt == 1) hipLaunchKernelGGL((KERNEL<1, 2>), grid, block, 0, s, a);                               \
+        else if (mt == 2 && nj == 1) hipLaunchKernelGGL((KERNEL<2, 1>), grid, block, 0, s, a);                    \
+        else if (mt == 2) hipLaunchKernelGGL((KERNEL<2, 2>), grid, block, 0, s, a);                               \
+        else if (nj == 1) hipLaunchKernelGGL((KERNEL<4, 1>), grid, block, 0, s, a);                               \
+        else hipLaunchKernelGGL((KERNEL<4, 2>), grid, block, 0, s, a);                                            \
+    } while (0)
+
 static bool bad_h(int H) { return !(H == 64 || H == 128 || H == 256 || H == 512 || H == 1024); }
 
 // Co-residency probe (called by a4nt_init with `device` current): what the occupancy calculator says about every
@@ -1010,16 +1043,18 @@ int a4nt_lstm_probe_occupancy(int device, int num_cus) {
     const int rcs = scratch_lookup(device);                          // a4nt_lstm_seq_fwd_noalloc's per-device buffer
     if (rcs != A4NT_OK) return rcs;
     A4NT_PROBE(1, 1); A4NT_PROBE(1, 2);
-    // 16 rows per group at H >= 256: the backward sweep is the 2-D kernel
-    A4NT_PROBE_K(1, 4, 0, lstm_fwd_kernel<1 A4NT_COMMA 4>, lstm_bwd2d_kernel<1>);
-    A4NT_PROBE_K(1, 8, 0, lstm_fwd_kernel<1 A4NT_COMMA 8>, lstm_bwd2d_kernel<2>);
-    A4NT_PROBE_K(1, 16, 0, lstm_fwd_kernel<1 A4NT_COMMA 16>, lstm_bwd2d_kernel<4>);
-    A4NT_PROBE(2, 1); A4NT_PROBE(2, 2); A4NT_PROBE(2, 4); A4NT_PROBE(2, 8); A4NT_PROBE(2, 16);
-    A4NT_PROBE(4, 1); A4NT_PROBE(4, 2); A4NT_PROBE(4, 4); A4NT_PROBE(4, 8); A4NT_PROBE(4, 16);
+    A4NT_PROBE(2, 1); A4NT_PROBE(2, 2);
+    A4NT_PROBE(4, 1); A4NT_PROBE(4, 2);
+    // H >= 256: the backward sweep is the 2-D kernel
+#define A4NT_PROBE_X(mt, nj) A4NT_PROBE_K(mt, nj, 0, lstm_fwd_kernel<mt A4NT_COMMA nj>, lstm_bwdx_kernel<nj / 4 A4NT_COMMA mt>)
+    A4NT_PROBE_X(1, 4); A4NT_PROBE_X(1, 8); A4NT_PROBE_X(1, 16);
+    A4NT_PROBE_X(2, 4); A4NT_PROBE_X(2, 8); A4NT_PROBE_X(2, 16);
+    A4NT_PROBE_X(4, 4); A4NT_PROBE_X(4, 8); A4NT_PROBE_X(4, 16);
     A4NT_PROBE2(1, 1); A4NT_PROBE2(1, 2);
-    A4NT_PROBE_K(1, 4, 1, lstm_fwd2_kernel<1 A4NT_COMMA 4>, lstm_bwd2d2_kernel<1>);
-    A4NT_PROBE_K(1, 8, 1, lstm_fwd2_kernel<1 A4NT_COMMA 8>, lstm_bwd2d2_kernel<2>);
-    A4NT_PROBE2(2, 1); A4NT_PROBE2(2, 2); A4NT_PROBE2(2, 4); A4NT_PROBE2(2, 8);
+    A4NT_PROBE2(2, 1); A4NT_PROBE2(2, 2);
+#define A4NT_PROBE_X2(mt, nj) A4NT_PROBE_K(mt, nj, 1, lstm_fwd2_kernel<mt A4NT_COMMA nj>, lstm_bwdx2_kernel<nj / 4 A4NT_COMMA mt>)
+    A4NT_PROBE_X2(1, 4); A4NT_PROBE_X2(1, 8);
+    A4NT_PROBE_X2(2, 4); A4NT_PROBE_X2(2, 8);
     return A4NT_OK;
 }
 // co-resident workgroups the probe found for the single-sweep instantiation (0 = not probed)
@@ -1051,6 +1086,22 @@ extern "C" int a4nt_lstm_sync_words(int B, int H) {
 }
 
 static bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+// the 2-D backward sweep fetches its step inputs with 16-byte LDS-DMA loads
+static bool bwdx_misaligned(const LstmBwdArgs& a) {
+    return misaligned(a.gates) || misaligned(a.cs) || (a.c0 && misaligned(a.c0)) || (a.dhs && misaligned(a.dhs));
+}
+#define A4NT_DISPATCH_BWDX(KERNEL, mt, nt, grid, block, s, a)                                                    \
+    do {                                                                                                         \
+        if (nt == 1 && mt == 1) hipLaunchKernelGGL((KERNEL<1, 1>), grid, block, 0, s, a);                         \
+        else if (nt == 1 && mt == 2) hipLaunchKernelGGL((KERNEL<1, 2>), grid, block, 0, s, a);                    \
+        else if (nt == 1) hipLaunchKernelGGL((KERNEL<1, 4>), grid, block, 0, s, a);                               \
+        else if (nt == 2 && mt == 1) hipLaunchKernelGGL((KERNEL<2, 1>), grid, block, 0, s, a);                    \
+        else if (nt == 2 && mt == 2) hipLaunchKernelGGL((KERNEL<2, 2>), grid, block, 0, s, a);                    \
+        else if (nt == 2) hipLaunchKernelGGL((KERNEL<2, 4>), grid, block, 0, s, a);                               \
+        else if (mt == 1) hipLaunchKernelGGL((KERNEL<4, 1>), grid, block, 0, s, a);                               \
+        else if (mt == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, block, 0, s, a);                               \
+        else hipLaunchKernelGGL((KERNEL<4, 4>), grid, block, 0, s, a);                                            \
+    } while (0)
 
 static int launch_seq_fwd(const char* what, int T, int B, int H, const float* gx, const float* gc, const float* whh,
                           const float* h0, const float* c0, const int* lens, float* hs, float* gates, float* cs, float* hN,
@@ -1208,10 +1259,12 @@ extern "C" int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const fl
     a.dgates = dgates; a.dh0 = dh0; a.dc0 = dc0; a.gxch = xch; a.sync = sync; a.tmo = sync + 32 * G;
     a.need_dh0 = (dh0 != nullptr) ? 1 : 0;
     dim3 grid(G * a.NW), block(256);
-    if (mt == 1 && H == 256) hipLaunchKernelGGL((lstm_bwd2d_kernel<1>), grid, block, 0, s, a);
-    else if (mt == 1 && H == 512) hipLaunchKernelGGL((lstm_bwd2d_kernel<2>), grid, block, 0, s, a);
-    else if (mt == 1 && H == 1024) hipLaunchKernelGGL((lstm_bwd2d_kernel<4>), grid, block, 0, s, a);
-    else A4NT_DISPATCH_LSTM(lstm_bwd_kernel, mt, H / 64, grid, block, s, a);
+    if (H >= 256) {
+        if (bwdx_misaligned(a)) { a4nt_set_error("a4nt_lstm_seq_bwd: gates / cs / c0 / dhs must be 16-byte aligned at H >= 256"); return A4NT_ERR_ARG; }
+        A4NT_DISPATCH_BWDX(lstm_bwdx_kernel, mt, H / 256, grid, block, s, a);
+    } else {
+        A4NT_DISPATCH_LSTM_SMALL(lstm_bwd_kernel, mt, H / 64, grid, block, s, a);
+    }
     return a4nt_check_launch("lstm_seq_bwd");
 }
 
@@ -1311,8 +1364,17 @@ extern "C" int a4nt_lstm_seq_bwd_pair(int H, const a4nt_lstm_bwd_problem* p0, co
     }
     const int nA = G[0] * (H / 16);
     dim3 grid((G[0] + G[1]) * (H / 16)), block(256);
-    if (mt == 1 && H == 256) hipLaunchKernelGGL((lstm_bwd2d2_kernel<1>), grid, block, 0, s, a[0], a[1], nA);
-    else if (mt == 1 && H == 512) hipLaunchKernelGGL((lstm_bwd2d2_kernel<2>), grid, block, 0, s, a[0], a[1], nA);
-    else A4NT_DISPATCH_LSTM2(lstm_bwd2_kernel, mt, H / 64, grid, block, s, a[0], a[1], nA);
+    if (H >= 256) {
+        if (bwdx_misaligned(a[0]) || bwdx_misaligned(a[1])) { a4nt_set_error("a4nt_lstm_seq_bwd_pair: gates / cs / c0 / dhs must be 16-byte aligned at H >= 256"); return A4NT_ERR_ARG; }
+        if (mt == 1 && H == 256) hipLaunchKernelGGL((lstm_bwdx2_kernel<1, 1>), grid, block, 0, s, a[0], a[1], nA);
+        else if (mt == 2 && H == 256) hipLaunchKernelGGL((lstm_bwdx2_kernel<1, 2>), grid, block, 0, s, a[0], a[1], nA);
+        else if (mt == 1) hipLaunchKernelGGL((lstm_bwdx2_kernel<2, 1>), grid, block, 0, s, a[0], a[1], nA);
+        else hipLaunchKernelGGL((lstm_bwdx2_kernel<2, 2>), grid, block, 0, s, a[0], a[1], nA);
+    } else {
+        if (mt == 1 && H == 64) hipLaunchKernelGGL((lstm_bwd2_kernel<1, 1>), grid, block, 0, s, a[0], a[1], nA);
+        else if (mt == 1) hipLaunchKernelGGL((lstm_bwd2_kernel<1, 2>), grid, block, 0, s, a[0], a[1], nA);
+        else if (H == 64) hipLaunchKernelGGL((lstm_bwd2_kernel<2, 1>), grid, block, 0, s, a[0], a[1], nA);
+        else hipLaunchKernelGGL((lstm_bwd2_kernel<2, 2>), grid, block, 0, s, a[0], a[1], nA);
+    }
     return a4nt_check_launch("lstm_seq_bwd_pair");
 }

@@ -1076,7 +1076,9 @@ extern "C" int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out) {
 extern "C" long long a4nt_lstm_xch_floats(int B, int H, int backward) {
     int mt, G;
     if (a4nt_lstm_geometry(B, H, &mt, &G) != A4NT_OK) return -1;
-    const long long per = (long long)G * (H / 16) * mt * 256;
+    // rows padded to the largest group size (64): covers the sweep's geometry under any workgroup budget and the
+    // decoder step's own choice of rows per workgroup (dec_geometry)
+    const long long per = (long long)((B + 63) / 64) * 64 * H;
     return 2 * per * (backward ? (H / 16) : 1);
 }
 extern "C" int a4nt_lstm_sync_words(int B, int H) {
@@ -1193,6 +1195,10 @@ extern "C" int a4nt_lstm_seq_fwd_noalloc(int T, int B, int H, const float* gx, c
                           tmo, mt, G, s);
 }
 
+// (A decoder step takes the sweep's geometry.  Larger row tiles -- fewer row groups, so fewer re-reads of W_hh per
+// launch -- were measured and are slower: 256 rows as 256 workgroups of 32 rows 55.3 us per decoding step against 53.8
+// as 512 workgroups of 16 rows; the step is bound by the latency of a workgroup's own weight fetch, merge and MFMA
+// chain, not by the L2 traffic of the fetches.)
 static int launch_dec_step(const char* what, int step, int B, int H, const float* cg, const float* ptab, const long long* tok,
                            const float* val, const float* whh, const float* c_prev, float* h_out, float* gates_out,
                            float* c_out, float* xch, const PgFinalArgs& fin, void* stream) {

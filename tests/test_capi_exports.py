@@ -50,6 +50,7 @@ def test_argument_errors_without_gpu():
     assert lib.a4nt_version() == 100
     assert lib.a4nt_lstm_xch_floats(128, 512, 0) == 2 * 8 * 32 * 256
     assert lib.a4nt_lstm_xch_floats(128, 512, 1) == 2 * 8 * 32 * 256 * 32     # [parity][group][consumer][producer] blocks
+    assert lib.a4nt_lstm_xch_floats(100, 512, 0) == 2 * 128 * 512             # rows padded to 64: any rows-per-group fits
     assert lib.a4nt_lstm_sync_words(128, 512) == 32 * 8 + 32
 
 

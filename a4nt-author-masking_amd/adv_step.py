@@ -189,7 +189,7 @@ class GradAllReducer(object):
     property of the graph and therefore the same on every rank.
     With world_size 1 (or no process group) every method is a no-op."""
 
-    def __init__(self, params, bucket_mb=32.0, group=None, overlap=None, force=False):
+    def __init__(self, params, bucket_mb=32.0, group=None, overlap=None, force=False, before_wait=None):
         import os
         import torch.distributed as dist
         self.dist = dist
@@ -200,6 +200,10 @@ class GradAllReducer(object):
         # gloo (the CPU stand-in for RCCL in the tests) gets host tensors: its own staging of device tensors has been
         # seen to stall when the GPU is busy (two ranks sharing one card), and it is not what this class is testing
         self.host_staged = self.on and dist.get_backend(group) == 'gloo'
+        # called at the top of wait() when an exchange is pending (tests pass ops.check_timeouts here: a persistent
+        # sweep of this rank that gave up waiting for a peer workgroup is then reported BEFORE the rank blocks in the
+        # collective, so a co-residency stall on a shared GPU cannot pass as a stall of the collective)
+        self.before_wait = before_wait
         self.params = [p for p in params]
         self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
         if overlap is None:
@@ -349,6 +353,8 @@ class GradAllReducer(object):
     def wait(self):
         """Finish the exchange: the averaged gradients are in place (the parameters' .grad are slices of the flat
         buckets)."""
+        if self._pending and self.before_wait is not None:
+            self.before_wait()
         for work, flat, wire in self._pending:
             work.wait()
             if wire is not flat:

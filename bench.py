@@ -126,6 +126,30 @@ def adv_step(impl, G, D, optG, optD, batches, it, batch, reducers, fused=True):
     return rd, rg
 
 
+def step_flops(workload, batch):
+    """Algorithmic FLOPs of one step (forward = 2 per multiply-add, backward with weight gradients =
+    2 x forward, data gradient only = 1 x forward; the hard Gumbel sample makes every soft-embedding FORWARD a gather,
+    its backward is the dense d(emb) x E^T).  Per token and sentence:
+      LSTM layer 8 H (I + H); vocabulary projection 2 H V; soft-embedding backward 2 V E; CharCNN sum_K 2 E F K.
+    Adversarial step: the D update runs the generation forward (enc + dec + proj) and the discriminator forward +
+    backward on the generated and the real batch; the G update runs the generation forward, the discriminator
+    forward + data gradient, its soft-embedding backward, the reconstruction pass (enc + dec + proj, forward + full
+    backward, + the soft-embedding backward of its input) and the generation's full backward with the per-step
+    soft-embedding backward: 7 gen + 8 disc + 3 softemb in all."""
+    Vv, A_ = V + 1, A
+    enc = 8.0 * H * (E + H)
+    dec = 8.0 * H * ((H + E + A_) + H)
+    proj = 2.0 * H * Vv
+    softemb = 2.0 * Vv * E
+    gen = enc + dec + proj
+    if WORKLOADS[workload]['disc'] == 'cnn':
+        disc = sum(2.0 * E * 100 * k for k in (2, 3, 4))
+    else:
+        disc = 2 * 8.0 * 512 * (512 + 512)                 # CharLstm 2 x 512 on E = 512 inputs
+    per_token = {'cfg1': 3 * disc, 'cfg2': 3 * gen}.get(workload, 7 * gen + 8 * disc + 3 * softemb)
+    return per_token * T * batch
+
+
 def cpu_baseline(batch_cpu=B):
     """The oracle (pure-PyTorch CPU restatement pinned to the reference by tests/golden) timed on
     this host's cores on a bounded sample: ONE adversarial step at the benchmark's batch (about 10-25 s
@@ -433,6 +457,10 @@ def main():
                            'speech-shaped ragged lens' if args.ragged else 'all lens=T'),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'losses_finite': loss_ok},
             'ranks_seen': ranks_seen,
+            # whole step against the fp32 matrix peak: algorithmic FLOPs of the step (step_flops) / wall time per step
+            'end_to_end': {'tflop_per_step_per_gpu': step_flops(args.workload, args.batch) / 1e12,
+                           'achieved_tflops_per_gpu': step_flops(args.workload, args.batch) / (dt / args.steps) / 1e12,
+                           'frac_of_fp32_mfma_peak': step_flops(args.workload, args.batch) / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS},
             'roofline': dict({'bound': 'mfma', 'traffic': pmc_traffic(timer['name']),
                               'kernel_chosen_from': roofline_source}, **main_rl),
         }

@@ -67,7 +67,11 @@ def _worker(rank, world, port, q, dump_path):
     b = Bfull // world
     r0, r1 = rank * b, (rank + 1) * b
     my_noise = [torch.cat([u[r0:r1], u[Bfull + r0:Bfull + r1]], 0) for u in noise]
-    reds = (impl.GradAllReducer(list(G.parameters()), bucket_mb=0.01), impl.GradAllReducer(list(D.parameters()), bucket_mb=0.01))
+    # before_wait: this rank's persistent sweeps are checked for a hand-off timeout (workgroups of two processes not
+    # co-resident) BEFORE it blocks in a collective -- such a stall fails here with its own message instead of looking
+    # like a stall of gloo
+    reds = (impl.GradAllReducer(list(G.parameters()), bucket_mb=0.01, before_wait=impl.check_timeouts),
+            impl.GradAllReducer(list(D.parameters()), bucket_mb=0.01, before_wait=impl.check_timeouts))
     out = None
     for it in range(2):                                   # second pass: buckets go out under backward()
         G.zero_grad(); D.zero_grad()

@@ -15,9 +15,9 @@ from collections import defaultdict
 NAMES = [(r'sgemm_kernel<false, false, 2, 2, \d, 1, true', 'sgemm_nn_128_nll'),
          (r'sgemm_kernel<false, true, 2', 'sgemm_nt_128'), (r'sgemm_kernel<true, false, 2', 'sgemm_tn_128'),
          (r'sgemm_kernel<false, false, 2', 'sgemm_nn_128'), (r'sgemm_kernel<.*, 1, 1, 4', 'sgemm_64'),
-         (r'lstm_fwd2_kernel', 'lstm_fwd_pair'), (r'lstm_bwd2d2_kernel|lstm_bwd2_kernel', 'lstm_bwd_pair'),
+         (r'lstm_fwd2_kernel', 'lstm_fwd_pair'), (r'lstm_bwdx2_kernel|lstm_bwd2_kernel', 'lstm_bwd_pair'),
          (r'lstm_dec_kernel', 'lstm_dec_step'), (r'lstm_fwd_kernel', 'lstm_fwd'),
-         (r'lstm_bwd2d_kernel|lstm_bwd_kernel', 'lstm_bwd'), (r'conv1d_kernel', 'conv1d'),
+         (r'lstm_bwdx_kernel|lstm_bwd_kernel', 'lstm_bwd'), (r'conv1d_kernel', 'conv1d'),
          (r'proj_gumbel_kernel', 'proj_gumbel'), (r'nt_rows_kernel', 'sgemm_nt_rows'), (r'skinny_kernel', 'sgemm_skinny')]
 
 

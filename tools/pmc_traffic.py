@@ -23,11 +23,11 @@ from collections import defaultdict
 LABELS = [
     (r'sgemm_kernel<(true|false), (true|false), (\d), \d, \d(?:, \d)?(?:, (?:true|false))?>', None),
     (r'lstm_fwd2_kernel', 'lstm_seq_fwd_pair'),
-    (r'lstm_bwd2d2_kernel|lstm_bwd2_kernel', 'lstm_seq_bwd_pair'),
+    (r'lstm_bwdx2_kernel|lstm_bwd2_kernel', 'lstm_seq_bwd_pair'),
     (r'nt_rows_kernel', 'sgemm_nt_rows'),
     (r'lstm_dec_kernel', 'lstm_dec_step'),
     (r'lstm_fwd_kernel', 'lstm_seq_fwd'),
-    (r'lstm_bwd2d_kernel|lstm_bwd_kernel', 'lstm_seq_bwd'),
+    (r'lstm_bwdx_kernel|lstm_bwd_kernel', 'lstm_seq_bwd'),
     (r'nll_grad_rows_kernel', 'nll_grad_rows'),
     (r'conv1d_kernel', 'conv1d'),
     (r'proj_gumbel_kernel', 'proj_gumbel'),

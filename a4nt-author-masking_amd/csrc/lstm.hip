@@ -1008,6 +1008,23 @@ static int pick_mt(int B, int NW, int* G) {
         else hipLaunchKernelGGL((KERNEL<4, 2>), grid, block, 0, s, a);                                            \
     } while (0)
 
+// (every instantiation up to H = 512)
+#define A4NT_DISPATCH_LSTM_TO8(KERNEL, mt, nj, grid, block, s, a)                                               \
+    do {                                                                                                         \
+        if (mt == 1 && nj == 1) hipLaunchKernelGGL((KERNEL<1, 1>), grid, block, 0, s, a);                         \
+        else if (mt == 1 && nj == 2) hipLaunchKernelGGL((KERNEL<1, 2>), grid, block, 0, s, a);                    \
+        else if (mt == 1 && nj == 4) hipLaunchKernelGGL((KERNEL<1, 4>), grid, block, 0, s, a);                    \
+        else if (mt == 1) hipLaunchKernelGGL((KERNEL<1, 8>), grid, block, 0, s, a);                               \
+        else if (mt == 2 && nj == 1) hipLaunchKernelGGL((KERNEL<2, 1>), grid, block, 0, s, a);                    \
+        else if (mt == 2 && nj == 2) hipLaunchKernelGGL((KERNEL<2, 2>), grid, block, 0, s, a);                    \
+        else if (mt == 2 && nj == 4) hipLaunchKernelGGL((KERNEL<2, 4>), grid, block, 0, s, a);                    \
+        else if (mt == 2) hipLaunchKernelGGL((KERNEL<2, 8>), grid, block, 0, s, a);                               \
+        else if (nj == 1) hipLaunchKernelGGL((KERNEL<4, 1>), grid, block, 0, s, a);                               \
+        else if (nj == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, block, 0, s, a);                               \
+        else if (nj == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, block, 0, s, a);                               \
+        else hipLaunchKernelGGL((KERNEL<4, 8>), grid, block, 0, s, a);                                            \
+    } while (0)
+
 static bool bad_h(int H) { return !(H == 64 || H == 128 || H == 256 || H == 512 || H == 1024); }
 
 // Co-residency probe (called by a4nt_init with `device` current): what the occupancy calculator says about every
@@ -1205,6 +1222,11 @@ static int launch_dec_step(const char* what, int step, int B, int H, const float
     int mt, G;
     int rc = a4nt_lstm_geometry(B, H, &mt, &G);
     if (rc != A4NT_OK) return rc;
+    // Nothing is handed over inside a decoder step's launch, so no residency rule binds it: at H = 1024 it runs 32
+    // rows per workgroup at most (the 64-row instantiation would carry the merge prologue on top of 256 weight
+    // registers and 64 accumulator registers, and spill).  A function of (B, H) alone: every step of a generation
+    // lays the hand-off buffer out the same way.
+    if (H == 1024 && mt == 4) { mt = 2; G = (B + 31) / 32; }
     if (!cg || !ptab || !whh || !h_out || !xch || misaligned(whh) || misaligned(xch)) {
         a4nt_set_error("%s: null or misaligned pointer", what);
         return A4NT_ERR_ARG;
@@ -1218,7 +1240,9 @@ static int launch_dec_step(const char* what, int step, int B, int H, const float
     a.fin = fin;
     dim3 grid(G * a.NW), block(256);
     hipStream_t s = (hipStream_t)stream;
-    A4NT_DISPATCH_LSTM(lstm_dec_kernel, mt, H / 64, grid, block, s, a);
+    if (mt == 2 && H == 1024) hipLaunchKernelGGL((lstm_dec_kernel<2, 16>), grid, block, 0, s, a);
+    else if (mt == 1 && H == 1024) hipLaunchKernelGGL((lstm_dec_kernel<1, 16>), grid, block, 0, s, a);
+    else A4NT_DISPATCH_LSTM_TO8(lstm_dec_kernel, mt, H / 64, grid, block, s, a);
     return a4nt_check_launch(what);
 }
 

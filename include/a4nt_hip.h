@@ -74,11 +74,14 @@ int a4nt_sgemm_skinny(int transB, int M, int N, int K, const float* A, int lda, 
 int a4nt_lstm_geometry(int B, int H, int* mt_out, int* groups_out);
 /* 512 (default: two workgroups per CU where the instantiation allows it; needs the GPU to itself) or
  * 256 (one per CU for every instantiation: leaves room for other streams' kernels, e.g. RCCL).  A setting of
- * the calling thread's current device. */
+ * the calling thread's current device, read at launch time by every sweep entry point: change it from one host
+ * thread per device at a time (two threads launching sweeps on one device while one of them switches the budget
+ * see each other's value). */
 int a4nt_lstm_set_max_workgroups(int n);
 /* Co-resident workgroups a4nt_init found for the <mt, H> single-sweep kernels on `device` (0: not probed). */
 int a4nt_lstm_resident_workgroups(int device, int mt, int H);
-long long a4nt_lstm_xch_floats(int B, int H, int backward);   /* exchange-buffer size (floats) */
+long long a4nt_lstm_xch_floats(int B, int H, int backward);   /* exchange-buffer size (floats): rows padded to 64, so
+                                                                 * one buffer serves every rows-per-group the budget may pick */
 int a4nt_lstm_sync_words(int B, int H);                       /* sync-block size (uint32 words) */
 
 /* Persistent forward sweep of ONE LSTM layer over T steps (W_hh resident in VGPRs, recurrent
@@ -118,6 +121,9 @@ int a4nt_lstm_seq_fwd_noalloc(int T, int B, int H, const float* gx, const float*
  * the pre-activation gates (zero where t >= lens[b]; may alias gates); weight / input gradients
  * are time-batched a4nt_sgemm calls over it.  dhs / dhN / dcN may be NULL.  dh0 NULL skips the
  * last recurrent product.  xch sized by a4nt_lstm_xch_floats(B,H,1).
+ * At H >= 256 gates, cs, c0 and dhs must be 16-byte aligned (the sweep fetches its step inputs with 16-byte
+ * LDS-DMA loads; A4NT_ERR_ARG otherwise).  All arrays are addressed with 64-bit arithmetic: T*B*4H*4 bytes may
+ * exceed 4 GiB.
  * Replaces: autograd backward of the nn.LSTM calls cited above. */
 int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const float* gates, const float* cs, const float* c0,
                       const int* lens, const float* dhs, const float* dhN, const float* dcN, float* dgates,

@@ -220,6 +220,7 @@ def _ref_lstm(x, lens, lstm, h0, c0, up, uph, upc):
                                             (3, 256, 16, 1024, False),
                                             (4, 100, 16, 1024, True), (4, 128, 16, 1024, False),   # one workgroup per CU at H=1024
                                             (3, 700, 16, 512, True),      # more rows than one sweep holds: chunked
+                                            (4, 600, 16, 256, True), (3, 900, 16, 256, True),   # H=256 at 32 / 64 rows per group
                                             (200, 256, 16, 1024, True),   # cfg 5's production geometry, full length
                                             (100, 256, 16, 512, True)])   # cfg 3's 2B-row sweeps, full length
 def test_lstm_layer_fwd_bwd(ops, T, B, I, H, ragged):

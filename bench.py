@@ -176,9 +176,12 @@ def cpu_baseline(batch_cpu=B):
                       'V=%d, oracle/ on torch CPU fp32, %.1f s' % (batch_cpu, B, T, V + 1, dt)}
 
 
-def _latest_profile(stem):
-    """profiles/rNN_<stem>.json of the latest round that has one."""
+def _latest_profile(stem, workload='adv'):
+    """profiles/rNN_<stem>.json (the metric's workload) or profiles/rNN_<workload>_<stem>.json of the latest round
+    that has one."""
     import glob
+    if workload != 'adv':
+        stem = '%s_%s' % (workload, stem)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s.json' % stem)))
     return files[-1] if files else None
 
@@ -212,11 +215,11 @@ def dominant_kernel(workload='adv'):
     return None
 
 
-def pmc_traffic(label):
+def pmc_traffic(label, workload='adv'):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and
     WRITE_SIZE runs of this same command); None when that kernel has no entry."""
-    path = _latest_profile('pmc_traffic')
+    path = _latest_profile('pmc_traffic', workload)
     if path is None:
         return None
     with open(path) as f:
@@ -225,12 +228,12 @@ def pmc_traffic(label):
     return ent['hbm_bytes_per_launch'] if ent else None
 
 
-def lstm_mfma_util():
+def lstm_mfma_util(workload='adv'):
     """BASELINE.json's second metric: matrix-pipe utilisation of the LSTM kernels (MFMA-busy cycles / (active cycles
     x 1024 SIMDs)) from the committed counter pass over this same command (profiles/rNN_pmc_mfma.json,
     tools/pmc_mfma.py).  Counters cannot be read from inside the timed run, so these are the committed profile's
     numbers, named with their source; None when no profile is committed."""
-    path = _latest_profile('pmc_mfma')
+    path = _latest_profile('pmc_mfma', workload)
     if path is None:
         return None
     with open(path) as f:
@@ -461,10 +464,10 @@ def main():
             'end_to_end': {'tflop_per_step_per_gpu': step_flops(args.workload, args.batch) / 1e12,
                            'achieved_tflops_per_gpu': step_flops(args.workload, args.batch) / (dt / args.steps) / 1e12,
                            'frac_of_fp32_mfma_peak': step_flops(args.workload, args.batch) / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS},
-            'roofline': dict({'bound': 'mfma', 'traffic': pmc_traffic(timer['name']),
+            'roofline': dict({'bound': 'mfma', 'traffic': pmc_traffic(timer['name'], args.workload),
                               'kernel_chosen_from': roofline_source}, **main_rl),
         }
-        util = lstm_mfma_util()
+        util = lstm_mfma_util(args.workload)
         if util is not None and args.workload in ('adv', 'cfg5'):
             line['lstm_mfma_util'] = util
         if others:

@@ -284,6 +284,8 @@ def maybe_self_launch(args, argv, environ=None, device_count=None, run=None):
     if args.gpus <= 1:
         return None
     have = torch.cuda.device_count() if device_count is None else device_count
+    if getattr(args, 'share_gpu', False):
+        have = args.gpus                 # rehearsal: every rank on device 0
     if args.gpus > have:
         raise SystemExit('bench.py: --gpus %d asked for, %d GPU(s) visible on this node' % (args.gpus, have))
     import subprocess
@@ -319,6 +321,10 @@ def main():
     ap.add_argument('--dp-rehearsal', action='store_true',
                     help='one GPU, but with the data-parallel machinery live: RCCL process group of one rank, gradient '
                          'buckets all-reduced under backward(), one LSTM workgroup per CU (what every rank of an N > 1 run does)')
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='rehearsal of the N > 1 path on a one-GPU box: every rank runs on device 0 and the collectives go '
+                         'over gloo (RCCL refuses two ranks on one device); use a small --batch so that the ranks\' '
+                         'persistent sweeps are co-resident.  The number is not a benchmark result.')
     args = ap.parse_args()
     rc = maybe_self_launch(args, sys.argv[1:])
     if rc is not None:
@@ -339,9 +345,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 and args.share_gpu:
+        dist.init_process_group('gloo')
+    elif world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     elif args.dp_rehearsal:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -355,7 +365,9 @@ def main():
     if args.py_loops:
         from a4nt_amd import gen_decode
         gen_decode.PY_LOOPS = True
-    if args.lstm_workgroups:
+    if args.share_gpu:
+        impl.lstm_set_max_workgroups(256)
+    elif args.lstm_workgroups:
         impl.lstm_set_max_workgroups(args.lstm_workgroups)
     elif world > 1 or args.dp_rehearsal:
         # leave half of every CU's registers to the RCCL kernels that run beside the persistent LSTM sweeps.  On the
@@ -415,12 +427,13 @@ def main():
     dt = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
     ops.check_timeouts()
-    tmax = torch.tensor([dt], device='cuda')
+    coll_dev = 'cpu' if args.share_gpu else 'cuda'
+    tmax = torch.tensor([dt], device=coll_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     # how many ranks the collective library really joined (1 without a process group)
-    seen = torch.ones(1, device='cuda')
+    seen = torch.ones(1, device=coll_dev)
     if world > 1 or args.dp_rehearsal:
         dist.all_reduce(seen, op=dist.ReduceOp.SUM)
     ranks_seen = int(seen.item())
@@ -458,7 +471,9 @@ def main():
             'config': {'workload': '%s, V=%d, E=%d, T=%d, batch %d/GPU, %s' % (
                            wl['text'], V + 1, E, T, args.batch,
                            'speech-shaped ragged lens' if args.ragged else 'all lens=T'),
-                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'losses_finite': loss_ok},
+                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'losses_finite': loss_ok,
+                       **({'rehearsal': 'all ranks share GPU 0, gloo collectives: not a benchmark result'}
+                          if args.share_gpu else {})},
             'ranks_seen': ranks_seen,
             # whole step against the fp32 matrix peak: algorithmic FLOPs of the step (step_flops) / wall time per step
             'end_to_end': {'tflop_per_step_per_gpu': step_flops(args.workload, args.batch) / 1e12,

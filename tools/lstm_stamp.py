@@ -24,19 +24,6 @@ for B in (128, 256):
     for n, v in zip(names, vals):
         print('   %-26s %8.1f per step  %5.1f%%' % (n, v / T, 100.0 * v / tot))
 
-# backward sweep
-bnames = ['cell backward + LDS + barrier', 'MFMA + publish stores issued', 'drain + barrier + signal',
-          'dgates store + next-step loads issued', 'wait for peers + barrier', 'partial loads landed + sums', 'LDS reduce', '-']
-for B in (128, 256):
-    w_hh = torch.randn(4 * H, H, device='cuda') * 0.04
-    gates = torch.rand(T, B, 4 * H, device='cuda'); cs = torch.randn(T, B, H, device='cuda'); dhs = torch.randn(T, B, H, device='cuda')
-    for it in range(3):
-        ops.lstm_seq_bwd(w_hh, gates, cs, None, None, dhs, None, None, False)
-    torch.cuda.synchronize()
-    xch, sync, g = ops._lstm_ws(gates.device, B, H, True)
-    words = sync[32 * g + 8: 32 * g + 24].cpu().numpy().astype('uint32')
-    vals = [int(words[2 * k]) | (int(words[2 * k + 1]) << 32) for k in range(8)]
-    tot = sum(vals)
-    print('backward B=%d  total %.0f ticks/step' % (B, tot / T))
-    for n, v in zip(bnames, vals):
-        print('   %-40s %8.1f per step  %5.1f%%' % (n, v / T, 100.0 * v / tot))
+# (The r03 backward sweep, lstm_bwdx_body, carries no phase stamps: it was tuned with ablation builds instead -- one part
+# of the step switched off per build, timed with tools/lstm_bench_b.py; DESIGN.md section 4.1.  The 1-D backward kernel
+# that serves H <= 128 still has them.)

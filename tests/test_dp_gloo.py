@@ -187,3 +187,65 @@ def test_two_reducers_ragged_tokens_equal_one_big_batch():
     for n, p in G.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         assert torch.allclose(torch.from_numpy(gG[n]), g, rtol=2e-5, atol=1e-7), 'G ' + n
+
+
+# ------------------------------------------------------------------------------------------------
+# persistent flat buckets: what happens to the parameters' .grad
+# ------------------------------------------------------------------------------------------------
+def _worker3(rank, world, port, out_q, overlap):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from a4nt_amd import GradAllReducer
+    torch.manual_seed(1)
+    used = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    unused = torch.nn.Parameter(torch.randn(4))            # never part of the graph: its gradient must stay None
+    extra = torch.nn.Parameter(torch.randn(3))             # gets a gradient from an EARLIER backward of the step
+    params = [used[0], unused, used[1], extra]
+    red = GradAllReducer(params, bucket_mb=1.0, overlap=overlap)
+    x = torch.arange(3.0) + rank
+    facts = {}
+    for it in range(3):
+        for p in params:
+            p.grad = None if it < 2 else (p.grad.zero_() if p.grad is not None else None)   # step 2: set_to_none=False
+        (extra * (rank + 1.0)).sum().backward()            # e.g. an ml_update pass before the armed backward
+        red.arm()
+        ((used[0] @ x).sum() * (rank + 1.0) + (used[1] ** 2).sum() + extra.sum()).backward()
+        red.launch()
+        red.wait()
+        facts[it] = dict(unused_none=unused.grad is None,
+                         in_bucket=[bool(red._is_view(red._index[id(p)])) for p in (used[0], used[1], extra)],
+                         g0=used[0].grad.clone().numpy(), g1=used[1].grad.clone().numpy(), ge=extra.grad.clone().numpy())
+    if rank == 0:
+        out_q.put((facts, used[1].detach().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('overlap', [False, True])
+def test_flat_buckets_keep_gradient_semantics(overlap):
+    """Gradients live in the persistent flat buckets after the exchange; a parameter no pass touched keeps a None
+    gradient (the optimizer must skip it as in a single-process run); a gradient accumulated by an earlier backward
+    of the same step is carried into the bucket; in-place zeroing (set_to_none=False) between steps works."""
+    import numpy as np
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29650 + (os.getpid() % 300) + (7 if overlap else 0)
+    procs = [ctx.Process(target=_worker3, args=(r, 2, port, q, overlap)) for r in range(2)]
+    for p in procs:
+        p.start()
+    facts, w1 = q.get(timeout=100)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # averages over ranks 0 and 1: d/dW0 of sum(W0 x_r)(r+1) = outer(1, x_r)(r+1); x_0 = [0,1,2], x_1 = [1,2,3]
+    g0 = (np.tile(np.arange(3.0), (5, 1)) * 1.0 + np.tile(np.arange(3.0) + 1.0, (5, 1)) * 2.0) / 2.0
+    ge = np.full(3, ((1.0 + 1.0) + (2.0 + 1.0)) / 2.0)       # earlier backward (r + 1) + the armed one (1)
+    for it in range(3):
+        f = facts[it]
+        assert f['unused_none'], 'step %d: untouched parameter got a gradient' % it
+        assert all(f['in_bucket']), 'step %d: gradients are not slices of the flat buckets' % it
+        np.testing.assert_allclose(f['g0'], g0, rtol=1e-6)
+        np.testing.assert_allclose(f['g1'], 2.0 * w1, rtol=1e-6)
+        np.testing.assert_allclose(f['ge'], ge, rtol=1e-6)

@@ -1,6 +1,8 @@
 """Oracle (test infrastructure): plain-loop restatement of DataProvider.prepare_data and of the two string
 windowing helpers of the reference's utils/data_provider.py (that file has Python-2 print statements and
-cannot be imported; the reference holds no test vectors for it: parity unpinned beyond this restatement).
+cannot be imported as it is; oracle/gen_golden_utils.py runs it through lib2to3 in memory and records
+tests/golden/utils_ref.npz from it, which pins the product's DataProvider -- and with it this restatement, which
+tests/test_data_eval.py compares the product with -- to the reference file).
 
   * prepare_data           utils/data_provider.py:310-348
   * rand_sentence          utils/data_provider.py:257-272

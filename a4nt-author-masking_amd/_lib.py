@@ -76,6 +76,10 @@ _SIGS = {
                                          P, P, P, P, c_longlong, P]),
     'a4nt_gen_loop_fwd': (c_int, [POINTER(GenFwdArgs), c_int, c_int, P]),
     'a4nt_gen_loop_bwd': (c_int, [POINTER(GenBwdArgs), P]),
+    'a4nt_gen_persist_ok': (c_int, [c_int, c_int, c_int]),
+    'a4nt_gen_persist_xch_floats': (c_longlong, [c_int, c_int]),
+    'a4nt_gen_persist_sync_words': (c_int, []),
+    'a4nt_gen_persist_fwd': (c_int, [POINTER(GenFwdArgs), c_int, c_int, P, P, P]),
     'a4nt_lstm_cell_bwd': (c_int, [c_int, c_int, P, P, P, P, c_int, c_longlong, P, c_int, P, P, P]),
     'a4nt_gumbel_fwd': (c_int, [c_int, c_int, P, c_int, P, c_int, c_ulonglong, c_uint, c_float, c_float, c_int, c_int,
                                 P, c_int, P, P, P, P, P, P, c_longlong, P, c_int, P]),

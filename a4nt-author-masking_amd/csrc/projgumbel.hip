@@ -25,6 +25,7 @@
 // straight-through value and updates done / gen_lens.  z is stored once (saved for the backward pass);
 // the logits never make a round trip through HBM.
 #include "gemm_stage.h"
+#include "pg_epilogue.h"
 
 #define PG_DEPTH 8        // 16-k blocks in flight per wave
 
@@ -168,6 +169,9 @@ __global__ __launch_bounds__(256 * (1 + NW)) void proj_gumbel_kernel(ProjGumbelA
 #pragma unroll
         for (int c = 0; c < 5; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    float bv[5];                                             // bias of this lane's 5 columns: in flight under the k loop
+#pragma unroll
+    for (int c = 0; c < 5; ++c) bv[c] = (a.bias && c0 + 5 * fr + c < a.N) ? a.bias[c0 + 5 * fr + c] : 0.f;
     const bool philox = !a.greedy && !a.U;
     constexpr int DEPTH = RT > 1 ? PG_DEPTH / 2 : PG_DEPTH;      // RT = 2: twice the MFMAs per block, half the ring
     PgBlock<RT, PACKED> ring[DEPTH];
@@ -212,68 +216,28 @@ __global__ __launch_bounds__(256 * (1 + NW)) void proj_gumbel_kernel(ProjGumbelA
         }
     }
 
-    // ---- epilogue: C layout of a 16x16 tile: col = lane&15, row = 4*(lane>>4) + reg; tile c = columns c0+5*fr+c
+    // injected uniforms (parity tests): the same transform, from memory
+    if (!a.greedy && a.U) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-    const int rbase = m0 + 16 * r + 4 * fq;                   // rows rbase .. rbase+3 (multiple of 4)
-    float zv[5][4];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-        const int col = c0 + 5 * fr + c;
-        const bool cvalid = col < a.N;
-        const float bv = (a.bias && cvalid) ? a.bias[col] : 0.f;
-        float g4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g4[e] = gn[r * 5 + c][e];
-        if (!a.greedy && a.U) {
+        for (int t = 0; t < RT * 5; ++t) {
+            const int r = t / 5, c = t % 5;
+            const int col = c0 + 5 * fr + c;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int row = rbase + e;
-                const float u = (row < a.M && cvalid) ? a.U[(long long)row * a.ldu + col] : 0.5f;
-                g4[e] = -logf(-logf(u + 1e-20f) + 1e-20f);
+                const int row = m0 + 16 * r + 4 * fq + e;
+                const float u = (row < a.M && col < a.N) ? a.U[(long long)row * a.ldu + col] : 0.5f;
+                gn[t][e] = -logf(-logf(u + 1e-20f) + 1e-20f);
             }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float xx = acc[r][c][e] + bv;
-            const float zz = a.greedy ? xx : (xx * a.scale + g4[e]);
-            const bool valid = cvalid && (rbase + e < a.M);
-            zv[c][e] = valid ? zz : -INFINITY;
-        }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int row = rbase + e;
-        if (a.z && row < a.M && row >= a.zrow0 && row - a.zrow0 < a.zrows) {
-            float* pz = a.z + (long long)(row - a.zrow0) * a.ldz + c0 + 5 * fr;
-#pragma unroll
-            for (int c = 0; c < 5; ++c)
-                if (c0 + 5 * fr + c < a.N) pz[c] = zv[c][e];
-        }
-        float m = -INFINITY; int mi = 0x7fffffff;
-#pragma unroll
-        for (int c = 0; c < 5; ++c)
-            if (zv[c][e] > m) { m = zv[c][e]; mi = c0 + 5 * fr + c; }
-        // reduce over the 16 lanes that share this row (lanes differ in fr only)
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            const float om = __shfl_xor(m, o);
-            const int oi = __shfl_xor(mi, o);
-            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
-        }
-        float s = 0.f;
-        if (!a.greedy) {
-#pragma unroll
-            for (int c = 0; c < 5; ++c) s += (zv[c][e] == -INFINITY) ? 0.f : expf((zv[c][e] - m) * a.inv_tau);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        }
-        if (fr == 0 && row < a.M) {
-            float* p = a.part + ((long long)row * a.nstrips + strip) * 4;
-            p[0] = m; p[1] = s; p[2] = __int_as_float(mi); p[3] = 0.f;
-        }
-    }
-    }
+    PgEpi ep;
+    ep.M = a.M; ep.N = a.N; ep.scale = a.scale; ep.inv_tau = a.inv_tau; ep.greedy = a.greedy;
+    ep.m0 = m0; ep.c0 = c0; ep.fr = fr; ep.fq = fq;
+    ep.z_on = a.z != nullptr; ep.zrow0 = a.zrow0; ep.zrows = a.zrows; ep.ldz = a.ldz;
+    ep.rz = make_rsrc(a.z, a.z ? clamp_bytes(((long long)(a.zrows - 1) * a.ldz + a.N) * 4) : 0u);
+    ep.rpart = make_rsrc(a.part, clamp_bytes((long long)a.M * a.nstrips * 16));
+    ep.nstrips = a.nstrips; ep.strip = strip;
+    pg_epilogue<RT, false>(ep, acc, bv, gn);
 }
 
 // Merge the strips of one row (online-softmax merge), then the sampler's bookkeeping (PgFinalArgs: common.h; the

@@ -31,6 +31,25 @@ _LOOP_LABELS = ('proj_gumbel', 'sgemm_nt_64', 'sgemm_nn_64', 'sgemm_nt_rows', 's
 
 
 PY_LOOPS = False          # benchmarks: drive the loops from Python even when nothing is being timed
+# The forward loop as one persistent launch (a4nt_gen_persist_fwd, csrc/genpersist.hip).  False (default): the per-step
+# launches -- measured on the box (tools/gen_fwd_time.py, 256 rows, H = 512, V = 10001): 54.5 us per step for the
+# persistent launch against 50.6 for the two launches per step; DESIGN.md section 7a has the phase stamps.  True:
+# whenever the shape fits; 'auto': above 128 rows.  Same results bit for bit either way (tests/test_hip_persist.py).
+PERSIST = False
+_persist_ws = {}
+
+
+def _persist_workspace(dev, B, H):
+    """Hand-off buffer and counters of the persistent generation kernel (one per device and shape)."""
+    from . import _lib
+    key = (dev.index, B, H)
+    if key not in _persist_ws:
+        lib = _lib.load()
+        xch = torch.zeros(int(lib.a4nt_gen_persist_xch_floats(B, H)), device=dev)
+        sync = torch.zeros(int(lib.a4nt_gen_persist_sync_words()), device=dev, dtype=torch.int32)
+        _persist_ws[key] = (xch, sync)
+        ops._sync_blocks.append((sync, 16))        # its timeout word is reported by ops.check_timeouts like a sweep's
+    return _persist_ws[key]
 
 
 def _native_loops():
@@ -253,10 +272,18 @@ class _GenDecode(Function):
             fa.z, fa.ldz, fa.zrow0, fa.zrows = (ops._p(ybuf), V, r0, r1 - r0) if need_grad else (None, 0, r0, 0)
             fa.part, fa.stats, fa.tok, fa.val_in, fa.val_out = ops._p(part), ops._p(stats), ops._p(tok), ops._p(val_in), ops._p(val_out)
             fa.gen_lens, fa.done, fa.end_c = ops._p(gen_lens), ops._p(done), int(cfg['end_c'])
+        persist = None
+        if native and PERSIST and W_packed is not None and not U_list and (PERSIST != 'auto' or B > 128) \
+                and lib.a4nt_gen_persist_ok(B, H, V):
+            persist = _persist_workspace(dev, B, H)
+            persist[0].zero_()
         chunk = n_max if cfg['end_c'] < 0 else CHECK_EVERY
         for c0 in range(0, n_max, chunk):
             c1 = min(n_max, c0 + chunk)
-            if native:
+            if persist is not None:
+                _lib.check(lib.a4nt_gen_persist_fwd(ctypes.byref(fa), c0, c1, ops._p(persist[0]), ops._p(persist[1]), s),
+                           'a4nt_gen_persist_fwd')
+            elif native:
                 _lib.check(lib.a4nt_gen_loop_fwd(ctypes.byref(fa), c0, c1, s), 'a4nt_gen_loop_fwd')
             else:
                 for t in range(c0, c1):

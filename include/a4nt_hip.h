@@ -214,6 +214,23 @@ typedef struct {
 int a4nt_gen_loop_fwd(const a4nt_gen_fwd_args* a, int t0, int t1, void* stream);
 int a4nt_gen_loop_bwd(const a4nt_gen_bwd_args* a, void* stream);
 
+/* Steps [t0, t1) of the generation loop as ONE persistent launch (csrc/genpersist.hip): the decoder's W_hh slices stay
+ * in registers for the whole range instead of being re-read by every decoder-step launch, the projection's first
+ * weight blocks are in flight when h_t arrives, and the recurrent product of step t+1 runs under the projection of
+ * step t; steps are chained by per-row-pair arrival counters (bounded waits; the sticky timeout word is
+ * sync[32*16], as for the sweeps).  Same arithmetic per element as a4nt_gen_loop_fwd: bit-identical results.
+ * Limits (a4nt_gen_persist_ok): B <= 256, H in {64, 128, 256, 512}, at most 256 workgroups (V <= 10240 above 128
+ * rows), a->W = the packed image of a4nt_proj_gumbel_pack (a->ldw = 0), Philox or greedy sampling (a->U = NULL).
+ * xch: a4nt_gen_persist_xch_floats(B, H) floats, zeroed before step 0 (the hand-off layout differs from
+ * a4nt_lstm_dec_step's: do not mix the two paths inside one generation); sync: a4nt_gen_persist_sync_words() words,
+ * zeroed once by the caller (launches clear the counters).  One launch at a time per (xch, sync), every workgroup
+ * must be resident: nothing else may occupy the device's CUs meanwhile.
+ * Replaces: the same lines as a4nt_gen_loop_fwd (models/char_translator.py:375-399). */
+int a4nt_gen_persist_ok(int B, int H, int V);
+long long a4nt_gen_persist_xch_floats(int B, int H);
+int a4nt_gen_persist_sync_words(void);
+int a4nt_gen_persist_fwd(const a4nt_gen_fwd_args* a, int t0, int t1, float* xch, unsigned* sync, void* stream);
+
 /* Element-wise cell backward of one decoder step (reverse loop of the generator):
  * dh = sum of n_slabs split-K partials [B][H] (slab_stride floats apart) + dh_b [B][ldb] (may be NULL). */
 int a4nt_lstm_cell_bwd(int B, int H, const float* gates, const float* c_t, const float* c_prev, const float* dh_slabs,

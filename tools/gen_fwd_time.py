@@ -45,6 +45,7 @@ def make(B, seed):
 
 
 def run(fa, stream):
+    keep['xch'].zero_()
     _lib.check(lib.a4nt_gen_loop_fwd(ctypes.byref(fa), 0, n_max, stream.cuda_stream), 'a4nt_gen_loop_fwd')
 
 
@@ -60,9 +61,34 @@ def timed(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
+def run_persist(fa, ws, stream):
+    ws[0].zero_()
+    _lib.check(lib.a4nt_gen_persist_fwd(ctypes.byref(fa), 0, n_max, ops._p(ws[0]), ops._p(ws[1]), stream.cuda_stream),
+               'a4nt_gen_persist_fwd')
+
+
 ops._ensure_init()
 main = torch.cuda.current_stream()
 for B in (256, 128):
     fa, keep = make(B, B)
     ms = timed(lambda: run(fa, main), reps=10)
     print('generation forward, %d rows: %.3f ms (%.1f us per step)' % (B, ms, ms * 1000.0 / n_max))
+    tok_steps = keep['tok'].clone()
+    ws = (torch.zeros(int(lib.a4nt_gen_persist_xch_floats(B, H)), device=dev),
+          torch.zeros(int(lib.a4nt_gen_persist_sync_words()), device=dev, dtype=torch.int32))
+    keep['xch'].zero_()
+    ms = timed(lambda: run_persist(fa, ws, main), reps=10)
+    print('  one persistent launch, %d rows: %.3f ms (%.1f us per step), tokens equal: %s, timeout word %d'
+          % (B, ms, ms * 1000.0 / n_max, bool(torch.equal(tok_steps, keep['tok'])), int(ws[1][32 * 16])))
+    st = ws[1][32 * 16 + 8: 32 * 16 + 64].cpu().numpy().astype('uint32')
+    if st.any():            # -DGP_STAMP build (tools/gp_stamp_build.sh): phase sums of workgroup 0's P wave 0 and L wave 0
+        for name, off, labels in (('P wave', 0, ['barrier 1', 'poll h_t', 'A loads + k loop', 'barriers 2-3', 'epilogue',
+                                                  'drain', 'barrier 4', 'noise']),
+                                  ('L wave', 24, ['poll strips + barrier 1', 'merge', 'gather + cell update',
+                                                  'barrier 2, publish, barrier 3', 'output stores', 'poll h_t', 'recurrent product',
+                                                  'barrier 4'])):
+            v = [int(st[off + 2 * k]) | (int(st[off + 2 * k + 1]) << 32) for k in range(8)]
+            tot = float(sum(v)) or 1.0
+            print('   %s (share of its step, x %.1f us):' % (name, ms * 1000.0 / n_max))
+            for lb, x in zip(labels, v):
+                print('      %-32s %5.1f %%  %6.2f us' % (lb, 100.0 * x / tot, x / tot * ms * 1000.0 / n_max))

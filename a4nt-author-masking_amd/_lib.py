@@ -80,6 +80,11 @@ _SIGS = {
     'a4nt_gen_persist_xch_floats': (c_longlong, [c_int, c_int]),
     'a4nt_gen_persist_sync_words': (c_int, []),
     'a4nt_gen_persist_fwd': (c_int, [POINTER(GenFwdArgs), c_int, c_int, P, P, P]),
+    'a4nt_mt_chunk_elems': (c_int, []),
+    'a4nt_mt_sumsq': (c_int, [c_int, P, P, P, P]),
+    'a4nt_mt_clip_coef': (c_int, [c_int, P, c_float, P, P]),
+    'a4nt_mt_scale': (c_int, [c_int, P, P, P, P]),
+    'a4nt_mt_rmsprop': (c_int, [c_int, P, P, c_float, c_float, c_float, c_float, P]),
     'a4nt_lstm_cell_bwd': (c_int, [c_int, c_int, P, P, P, P, c_int, c_longlong, P, c_int, P, P, P]),
     'a4nt_gumbel_fwd': (c_int, [c_int, c_int, P, c_int, P, c_int, c_ulonglong, c_uint, c_float, c_float, c_int, c_int,
                                 P, c_int, P, P, P, P, P, P, c_longlong, P, c_int, P]),

@@ -161,8 +161,8 @@ def _cycle_loss_fn(kind):
 
 def make_optimizers(modelGen, modelEval, lr_gen=1e-4, lr_eval=1e-3, decay_rate=0.99, smooth_eps=1e-8):
     """train_adversarial_translator.py:306-312."""
-    optimGen = torch.optim.RMSprop(modelGen.parameters(), lr=lr_gen, alpha=decay_rate, eps=smooth_eps)
-    optimEval = torch.optim.RMSprop(
+    optimGen = ops.RMSprop(modelGen.parameters(), lr=lr_gen, alpha=decay_rate, eps=smooth_eps)
+    optimEval = ops.RMSprop(
         [{'params': [p for n, p in modelEval.named_parameters() if n != 'decoder_W']},
          {'params': [modelEval.decoder_W], 'weight_decay': 0.0}],
         lr=lr_eval, alpha=decay_rate, eps=smooth_eps)
@@ -564,7 +564,7 @@ def g_update(modelGen, modelEval, optimGen, batch, c_aid, end_c, maxlen, temp, a
     if reducer is not None:
         reducer.launch()
         reducer.wait()
-    gnorm = torch.nn.utils.clip_grad_norm_(modelGen.parameters(), grad_clip)
+    gnorm = ops.clip_grad_norm_(modelGen.parameters(), grad_clip)
     if step:
         optimGen.step()
     res = {'loss': loss_tot.detach(), 'loss_gan': loss_gan.detach(), 'cyc_loss': cyc_loss.detach(),

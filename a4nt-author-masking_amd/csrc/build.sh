@@ -8,7 +8,7 @@ if [ "$1" = "--clean" ]; then rm -f ./*.o ../liba4nt_hip.so; fi
 FLAGS="-O3 -std=c++17 --offload-arch=$ARCH -fPIC -fno-gpu-rdc -Wno-unused-result"
 OBJS=""
 pids=()
-for f in capi sgemm skinny ntrows lstm rows misc projgumbel conv1d genloop genpersist; do
+for f in capi sgemm skinny ntrows lstm rows misc projgumbel conv1d genloop genpersist optim; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ gemm_stage.h -nt $f.o ] || [ pg_epilogue.h -nt $f.o ] || [ ../../include/a4nt_hip.h -nt $f.o ]; then
     hipcc $FLAGS -c $f.hip -o $f.o &
     pids+=($!)

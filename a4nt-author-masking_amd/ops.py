@@ -1015,3 +1015,84 @@ class _GumbelDense(Function):
 
 def gumbel_dense(x, U, seed, step, tau, hard):
     return _GumbelDense.apply(x, U, seed, step, tau, hard)
+
+
+# ----------------------------------------------------------------------------------------------
+# optimizer step as multi-tensor launches (csrc/optim.hip)
+# ----------------------------------------------------------------------------------------------
+_mt_plans = {}
+
+
+def _mt_plan(dev, numels):
+    """Chunk map of a tensor list (depends on the sizes only: built and uploaded once)."""
+    key = (dev.index, tuple(numels))
+    if key not in _mt_plans:
+        ch = int(_lib.load().a4nt_mt_chunk_elems())
+        rows = [(ti, c) for ti, n in enumerate(numels) for c in range((n + ch - 1) // ch)]
+        m = torch.tensor(rows, dtype=torch.int32).reshape(-1, 2)
+        _mt_plans[key] = (h2d(m, dev).contiguous(), len(rows), torch.empty(max(1, len(rows)), device=dev))
+    return _mt_plans[key]
+
+
+def _mt_ok(ts):
+    return all(t is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and not t.is_sparse for t in ts)
+
+
+def _mt_table(rows, dev):
+    """[p, g, sq, n] rows -> device (pinned staging: the host does not wait for the GPU)."""
+    return h2d(torch.tensor(rows, dtype=torch.int64), dev)
+
+
+def clip_grad_norm_(parameters, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (2-norm) in three launches: per-chunk sums of squares, norm + clipping factor on
+    the device, in-place scaling when the factor is below one.  Returns the total norm (0-dim device tensor)."""
+    ps = [p for p in parameters if p.grad is not None]
+    grads = [p.grad for p in ps]
+    if not grads or not _mt_ok(grads) or len({g.device for g in grads}) != 1:
+        return torch.nn.utils.clip_grad_norm_(ps, max_norm)
+    lib = _lib.load()
+    dev = grads[0].device
+    cmap, nchunks, partial = _mt_plan(dev, [g.numel() for g in grads])
+    table = _mt_table([[0, g.data_ptr(), 0, g.numel()] for g in grads], dev)
+    out2 = torch.empty(2, device=dev)
+    s = _s()
+    check(lib.a4nt_mt_sumsq(nchunks, _p(table), _p(cmap), _p(partial), s), 'a4nt_mt_sumsq')
+    check(lib.a4nt_mt_clip_coef(nchunks, _p(partial), float(max_norm), _p(out2), s), 'a4nt_mt_clip_coef')
+    check(lib.a4nt_mt_scale(nchunks, _p(table), _p(cmap), _p(out2), s), 'a4nt_mt_scale')
+    return out2[0]
+
+
+class RMSprop(torch.optim.RMSprop):
+    """torch.optim.RMSprop (same constructor, param_groups and state_dict: 'step', 'square_avg') whose step is ONE
+    launch per parameter group on GPU tensors (a4nt_mt_rmsprop).  Options the kernel does not cover (momentum, centered,
+    maximize, non-fp32 / non-contiguous / CPU tensors) take torch's implementation."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        plain = all(g['momentum'] == 0 and not g['centered'] and not g.get('maximize', False) and
+                    not g.get('capturable', False) and not g.get('differentiable', False) for g in self.param_groups)
+        todo = []
+        for g in self.param_groups:
+            ps = [p for p in g['params'] if p.grad is not None]
+            if ps:
+                todo.append((g, ps))
+        if closure is not None or not plain or not all(_mt_ok(ps) and _mt_ok([p.grad for p in ps]) for _, ps in todo):
+            return super().step(closure)
+        lib = _lib.load()
+        for g, ps in todo:
+            rows = []
+            for p in ps:
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = torch.zeros((), dtype=torch.float32)
+                    st['square_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['step'] += 1
+                if not _mt_ok([st['square_avg']]):
+                    raise A4NTError('RMSprop: square_avg must be a contiguous fp32 GPU tensor')
+                rows.append([p.data_ptr(), p.grad.data_ptr(), st['square_avg'].data_ptr(), p.numel()])
+            dev = ps[0].device
+            cmap, nchunks, _ = _mt_plan(dev, [p.numel() for p in ps])
+            table = _mt_table(rows, dev)
+            check(lib.a4nt_mt_rmsprop(nchunks, _p(table), _p(cmap), float(g['lr']), float(g['alpha']), float(g['eps']),
+                                      float(g['weight_decay']), _s()), 'a4nt_mt_rmsprop')
+        return None

@@ -104,7 +104,7 @@ def ml_step(impl, G, optG, batches, it, batch):
     optG.zero_grad()
     loss = G.forward_mltrain_loss(inps, lens, inps, lens, targs, auths=auths)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(G.parameters(), 10.0)
+    impl.ops.clip_grad_norm_(G.parameters(), 10.0)
     optG.step()
     return {'loss': loss.detach()}, {'loss': loss.detach()}
 
@@ -392,9 +392,9 @@ def main():
     if G is not None and D is not None:
         optG, optD = impl.make_optimizers(G, D)
     elif G is not None:
-        optG, optD = torch.optim.RMSprop(G.parameters(), lr=1e-4, alpha=0.99, eps=1e-8), None
+        optG, optD = impl.ops.RMSprop(G.parameters(), lr=1e-4, alpha=0.99, eps=1e-8), None
     else:
-        optG, optD = None, torch.optim.RMSprop(D.parameters(), lr=1e-3, alpha=0.99, eps=1e-8)
+        optG, optD = None, impl.ops.RMSprop(D.parameters(), lr=1e-3, alpha=0.99, eps=1e-8)
     force = bool(args.dp_rehearsal)
     reducers = (impl.GradAllReducer(list(G.parameters()), force=force) if G is not None else None,
                 impl.GradAllReducer(list(D.parameters()), force=force) if D is not None else None)

@@ -231,6 +231,22 @@ long long a4nt_gen_persist_xch_floats(int B, int H);
 int a4nt_gen_persist_sync_words(void);
 int a4nt_gen_persist_fwd(const a4nt_gen_fwd_args* a, int t0, int t1, float* xch, unsigned* sync, void* stream);
 
+/* Optimizer step of an update as multi-tensor launches (csrc/optim.hip).  `table`: device array of
+ * {float* p, float* g, float* sq, long long n} rows, one per tensor (32 bytes each); `map`: device int pairs
+ * (tensor row, chunk index inside it), one per workgroup, chunks of a4nt_mt_chunk_elems() elements.
+ *   a4nt_mt_sumsq     partial[c] = sum of g^2 over chunk c (fixed order)
+ *   a4nt_mt_clip_coef out2[0] = sqrt(sum of partial) = the global 2-norm, out2[1] = min(1, max_norm / (norm + 1e-6))
+ *   a4nt_mt_scale     g *= coef2[1] where it is below 1 (what clip_grad_norm_ leaves in .grad); no traffic otherwise
+ *   a4nt_mt_rmsprop   (g += wd*p;) sq = alpha*sq + (1-alpha)*g*g; p -= lr * g / (sqrt(sq) + eps)
+ * Nothing is read back by the host.  Replaces: torch.nn.utils.clip_grad_norm and the two torch.optim.RMSprop steps of
+ * train_adversarial_translator.py:306-312, :542, :730-731 (one launch per elementary operation there). */
+int a4nt_mt_chunk_elems(void);
+int a4nt_mt_sumsq(int nchunks, const void* table, const int* map, float* partial, void* stream);
+int a4nt_mt_clip_coef(int nchunks, const float* partial, float max_norm, float* out2, void* stream);
+int a4nt_mt_scale(int nchunks, const void* table, const int* map, const float* coef2, void* stream);
+int a4nt_mt_rmsprop(int nchunks, const void* table, const int* map, float lr, float alpha, float eps, float weight_decay,
+                    void* stream);
+
 /* Element-wise cell backward of one decoder step (reverse loop of the generator):
  * dh = sum of n_slabs split-K partials [B][H] (slab_stride floats apart) + dh_b [B][ldb] (may be NULL). */
 int a4nt_lstm_cell_bwd(int B, int H, const float* gates, const float* c_t, const float* c_prev, const float* dh_slabs,

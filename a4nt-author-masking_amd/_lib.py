@@ -80,6 +80,8 @@ _SIGS = {
     'a4nt_gen_persist_xch_floats': (c_longlong, [c_int, c_int]),
     'a4nt_gen_persist_sync_words': (c_int, []),
     'a4nt_gen_persist_fwd': (c_int, [POINTER(GenFwdArgs), c_int, c_int, P, P, P]),
+    'a4nt_bce_logits_fwd': (c_int, [c_int, c_int, c_int, P, c_float, P, P, P]),
+    'a4nt_bce_logits_bwd': (c_int, [c_int, c_int, c_int, P, c_float, P, P, P, P]),
     'a4nt_mt_chunk_elems': (c_int, []),
     'a4nt_mt_sumsq': (c_int, [c_int, P, P, P, P]),
     'a4nt_mt_clip_coef': (c_int, [c_int, P, c_float, P, P]),

@@ -120,7 +120,7 @@ def gan_generator_loss(logits, targ_aid, wasserstein=False, maximize_entropy=0, 
     if wasserstein:
         return -gen_aid_out.mean()
     if not maximize_entropy:
-        loss_aid = F.binary_cross_entropy_with_logits(gen_aid_out, torch.ones_like(gen_aid_out), weight=sample_weight)
+        loss_aid = ops.bce_with_logits_col(logits, targ_aid, 1.0, sample_weight)
     elif maximize_entropy == 1:
         p = torch.sigmoid(gen_aid_out)
         loss_aid = 4. * (p * torch.log(p) + (1. - p) * torch.log(1. - p)).mean()
@@ -422,8 +422,8 @@ def d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c,
         reducer.arm()
     if not wasserstein:
         if maximize_entropy == 0:
-            loss = (F.binary_cross_entropy_with_logits(real_aid_out, torch.ones_like(real_aid_out)) +
-                    F.binary_cross_entropy_with_logits(gen_aid_out, torch.zeros_like(gen_aid_out)))
+            loss = (ops.bce_with_logits_col(eval_out_gt[0], targ_aid, 1.0) +
+                    ops.bce_with_logits_col(outs[0], targ_aid, 0.0))
         else:
             n, dev = real_aid_out.shape[0], real_aid_out.device
             loss = (F.cross_entropy(eval_out_gt[0], torch.full((n,), 1 - c_aid, dtype=torch.long, device=dev)) +

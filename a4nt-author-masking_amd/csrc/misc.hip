@@ -326,3 +326,54 @@ extern "C" int a4nt_lrelu_maxtime_bwd(int Tout, int B, int F, float* pre, int ld
                        dfeat, ldf, argmax);
     return a4nt_check_launch("lrelu_maxtime_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------
+// binary cross-entropy with logits on one column of a [N][C] logit matrix against a constant target
+// (train_adversarial_translator.py:487-489, :690: BCEWithLogitsLoss of the discriminator's score for one author
+// against ones / zeros, optionally weighted per sample), mean over the N samples.  torch runs it as a dozen
+// element-wise launches on 128 numbers; here: one launch each way.
+//   loss = mean_n w_n * (max(x_n, 0) - x_n * y + log1p(exp(-|x_n|)))
+//   dx_n = g * w_n * (sigmoid(x_n) - y) / N        (written into column `col` of dlogits, zeros elsewhere)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_logits_fwd_kernel(int N, int C, int col, const float* x, float y, const float* w,
+                                                             float* loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float v = x[(long long)n * C + col];
+        const float l = fmaxf(v, 0.f) - v * y + log1pf(expf(-fabsf(v)));
+        s += w ? w[n] * l : l;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)N;
+}
+__global__ __launch_bounds__(256) void bce_logits_bwd_kernel(int N, int C, int col, const float* x, float y, const float* w,
+                                                             const float* gout, float* dx) {
+    const float g = gout[0] / (float)N;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N * C; i += gridDim.x * 256) {
+        const int n = i / C, c = i - n * C;
+        float d = 0.f;
+        if (c == col) {
+            const float v = x[i];
+            d = g * (1.0f / (1.0f + expf(-v)) - y);
+            if (w) d *= w[n];
+        }
+        dx[i] = d;
+    }
+}
+extern "C" int a4nt_bce_logits_fwd(int N, int C, int col, const float* logits, float target, const float* weight, float* loss,
+                                   void* stream) {
+    if (N <= 0 || C <= 0 || col < 0 || col >= C || !logits || !loss) { a4nt_set_error("a4nt_bce_logits_fwd: bad arguments"); return A4NT_ERR_ARG; }
+    hipLaunchKernelGGL(bce_logits_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, N, C, col, logits, target, weight, loss);
+    return a4nt_check_launch("bce_logits_fwd");
+}
+extern "C" int a4nt_bce_logits_bwd(int N, int C, int col, const float* logits, float target, const float* weight,
+                                   const float* grad_loss, float* dlogits, void* stream) {
+    if (N <= 0 || C <= 0 || col < 0 || col >= C || !logits || !grad_loss || !dlogits) { a4nt_set_error("a4nt_bce_logits_bwd: bad arguments"); return A4NT_ERR_ARG; }
+    const int grid = (N * C + 255) / 256 < 64 ? (N * C + 255) / 256 : 64;
+    hipLaunchKernelGGL(bce_logits_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C, col, logits, target, weight,
+                       grad_loss, dlogits);
+    return a4nt_check_launch("bce_logits_bwd");
+}

@@ -1096,3 +1096,38 @@ class RMSprop(torch.optim.RMSprop):
             check(lib.a4nt_mt_rmsprop(nchunks, _p(table), _p(cmap), float(g['lr']), float(g['alpha']), float(g['eps']),
                                       float(g['weight_decay']), _s()), 'a4nt_mt_rmsprop')
         return None
+
+
+class _BceLogitsCol(Function):
+    """mean_n w_n * BCEWithLogits(logits[n, col], target): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, logits, col, target, weight):
+        lib = _lib.load()
+        x = _f32(logits, 'bce logits').contiguous()
+        w = None if weight is None else _f32(weight, 'bce weight').contiguous()
+        N, C = x.shape
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        check(lib.a4nt_bce_logits_fwd(N, C, int(col), _p(x), float(target), _p(w), _p(loss), _s()), 'a4nt_bce_logits_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.col, ctx.target = int(col), float(target)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        N, C = x.shape
+        dx = torch.empty_like(x)
+        g = g.contiguous().view(1)
+        check(_lib.load().a4nt_bce_logits_bwd(N, C, ctx.col, _p(x), ctx.target, _p(w), _p(g), _p(dx), _s()),
+              'a4nt_bce_logits_bwd')
+        return dx, None, None, None
+
+
+def bce_with_logits_col(logits, col, target, weight=None):
+    """F.binary_cross_entropy_with_logits(logits[:, col], full_like(.., target), weight=weight) for [N, C] logits on the
+    GPU (anything else: torch's own)."""
+    if logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and (weight is None or weight.is_cuda):
+        return _BceLogitsCol.apply(logits, col, target, weight)
+    x = logits[:, col]
+    return torch.nn.functional.binary_cross_entropy_with_logits(x, torch.full_like(x, float(target)), weight=weight)

@@ -231,6 +231,15 @@ long long a4nt_gen_persist_xch_floats(int B, int H);
 int a4nt_gen_persist_sync_words(void);
 int a4nt_gen_persist_fwd(const a4nt_gen_fwd_args* a, int t0, int t1, float* xch, unsigned* sync, void* stream);
 
+/* Binary cross-entropy with logits of column `col` of logits [N][C] against the constant `target` (0 or 1), optional
+ * per-sample weights [N], mean over N -> loss[0]; backward: dlogits [N][C] = grad_loss[0] * d(loss)/d(logits) (zeros
+ * outside the column).  One launch each way.
+ * Replaces: nn.BCEWithLogitsLoss on eval_out[:, targ_aid] (train_adversarial_translator.py:487-489, :690). */
+int a4nt_bce_logits_fwd(int N, int C, int col, const float* logits, float target, const float* weight, float* loss,
+                        void* stream);
+int a4nt_bce_logits_bwd(int N, int C, int col, const float* logits, float target, const float* weight,
+                        const float* grad_loss, float* dlogits, void* stream);
+
 /* Optimizer step of an update as multi-tensor launches (csrc/optim.hip).  `table`: device array of
  * {float* p, float* g, float* sq, long long n} rows, one per tensor (32 bytes each); `map`: device int pairs
  * (tensor row, chunk index inside it), one per workgroup, chunks of a4nt_mt_chunk_elems() elements.

@@ -81,3 +81,24 @@ def test_rmsprop_falls_back_for_other_options():
     ob.step()
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('N,C,col,target,weighted', [(128, 2, 1, 1.0, False), (128, 2, 0, 0.0, False), (37, 3, 2, 1.0, True),
+                                                     (2, 2, 0, 0.0, True), (700, 2, 1, 0.0, False)])
+def test_bce_with_logits_col(N, C, col, target, weighted):
+    """ops.bce_with_logits_col against F.binary_cross_entropy_with_logits on the column view (loss and gradient)."""
+    import a4nt_amd
+    from a4nt_amd import ops
+    g = torch.Generator().manual_seed(N + col)
+    x0 = (torch.randn(N, C, generator=g) * 4.0)
+    x0[0, col] = 30.0                      # saturated either way
+    x0[N - 1, col] = -30.0
+    w = torch.rand(N, generator=g).cuda() if weighted else None
+    a = x0.clone().cuda().requires_grad_(True)
+    b = x0.clone().cuda().requires_grad_(True)
+    la = torch.nn.functional.binary_cross_entropy_with_logits(a[:, col], torch.full((N,), target, device='cuda'), weight=w)
+    lb = ops.bce_with_logits_col(b, col, target, w)
+    (3.0 * la).backward()
+    (3.0 * lb).backward()
+    assert_close(lb, la, 2e-6, 'loss')
+    assert_close(b.grad, a.grad, 2e-6, 'gradient')

@@ -83,3 +83,51 @@ def both():
 
 
 print('both, two streams  : %.2f ms' % timed(both))
+
+
+# ---- CU-masked streams (hipExtStreamCreateWithCUMask): the GEMMs confined to part of the chip -------------------------
+# r03 on the box: loop 6.57 ms, GEMMs 2.00 ms, two plain streams 8.82 ms; GEMMs masked to CUs 128-255 (3.83 ms alone)
+# beside the loop on all CUs 8.91 ms -- the loop's one-workgroup-per-CU launches wait for a GEMM tile to leave each of
+# those CUs; loop on CUs 0-127 (11.64 ms alone: its kernels are sized for 256 CUs) beside the GEMMs on the other half
+# 12.62 ms.  Nothing to gain from deferring weight gradients beside the loop.
+hip = ctypes.CDLL('libamdhip64.so')
+
+
+def masked_stream(words):
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    s = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(s), ctypes.c_uint32(len(words)), arr)
+    assert rc == 0, 'hipExtStreamCreateWithCUMask -> %d' % rc
+    return torch.cuda.ExternalStream(s.value)
+
+
+FULL = 0xffffffff
+for name, loop_mask, gemm_mask in (('loop on all CUs, GEMMs on CUs 128-255', None, [0, 0, 0, 0, FULL, FULL, FULL, FULL]),
+                                   ('loop on CUs 0-127, GEMMs on CUs 128-255', [FULL] * 4 + [0] * 4, [0] * 4 + [FULL] * 4)):
+    ls = hi if loop_mask is None else masked_stream(loop_mask)
+    gs = masked_stream(gemm_mask)
+
+    def gemms_on():
+        with torch.cuda.stream(gs):
+            gemms()
+
+    def both_masked():
+        ls.wait_stream(main)
+        gs.wait_stream(main)
+        loop(ls)
+        gemms_on()
+        main.wait_stream(ls)
+        main.wait_stream(gs)
+
+    def loop_only():
+        ls.wait_stream(main)
+        loop(ls)
+        main.wait_stream(ls)
+
+    def gemms_only():
+        gs.wait_stream(main)
+        gemms_on()
+        main.wait_stream(gs)
+
+    print('%s: loop alone %.2f ms, GEMMs alone %.2f ms, together %.2f ms'
+          % (name, timed(loop_only), timed(gemms_only), timed(both_masked)))

@@ -110,3 +110,17 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+
+// DPP row rotation inside the 16-lane rows of a wave: lane l reads lane (l + n) % 16 of its row -- one VALU instruction
+// where __shfl_xor is an LDS-crossbar round trip.  For lane 0 of a row a rotation by 8 / 4 / 2 / 1 IS the xor partner, so
+// a sum reduced by rotations 8, 4, 2, 1 is bit-identical, in lane 0, to the xor butterfly's.
+template <int CTRL>
+__device__ __forceinline__ float pg_dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int pg_dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+#define PG_ROR(n) (0x120 + (n))       // dpp_ctrl row_ror:n -- lane l of a 16-lane row reads lane (l + n) % 16
+

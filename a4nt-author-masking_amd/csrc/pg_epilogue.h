@@ -12,16 +12,6 @@
 #pragma once
 #include "gemm_stage.h"
 
-template <int CTRL>
-__device__ __forceinline__ float pg_dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int pg_dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
-}
-#define PG_ROR(n) (0x120 + (n))       // dpp_ctrl row_ror:n -- lane l of a 16-lane row reads lane (l + n) % 16
-
 __device__ __forceinline__ void pg_st1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)off, 0, 0);
 }

@@ -223,13 +223,21 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
                     v[j] = col < g.N ? acc[i][j][r] + bcol[j] : -INFINITY;
                     m = fmaxf(m, v[j]);
                 }
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                // over the 32 lanes of the half wave: the xor-16 partner through the crossbar, then DPP rotations inside
+                // the 16-lane rows (lane 0 of a row: the same operands in the same order as the xor butterfly)
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, pg_dpp_f<PG_ROR(8)>(m));
+                m = fmaxf(m, pg_dpp_f<PG_ROR(4)>(m));
+                m = fmaxf(m, pg_dpp_f<PG_ROR(2)>(m));
+                m = fmaxf(m, pg_dpp_f<PG_ROR(1)>(m));
                 float e = 0.f;
 #pragma unroll
                 for (int j = 0; j < WN; ++j) e += (v[j] == -INFINITY) ? 0.f : expf(v[j] - m);
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) e += __shfl_xor(e, o);
+                e += __shfl_xor(e, 16);
+                e += pg_dpp_f<PG_ROR(8)>(e);
+                e += pg_dpp_f<PG_ROR(4)>(e);
+                e += pg_dpp_f<PG_ROR(2)>(e);
+                e += pg_dpp_f<PG_ROR(1)>(e);
                 const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if ((lane & 31) == 0 && row < g.M) {
                     float* q = g.part + ((long long)row * g.nparts + p) * 2;

@@ -7,18 +7,21 @@
 // 1.7 us of matrix work).  Here the same arithmetic (same operand order per element: the results are bit-identical to
 // the per-step kernels') runs inside one launch of at most 256 workgroups of 8 waves, one per CU:
 //   * waves 4-7 ("L waves") are an LSTM workgroup of the decoder-step kernel at 32 rows per group: unit block j of row
-//     pair gp, W_hh slice resident in VGPRs for the WHOLE generation, cell state in registers; they also draw the
-//     Philox Gumbel noise of the workgroup's projection tiles (what the per-step kernel's noise waves do);
+//     pair gp, W_hh slice resident in VGPRs for the WHOLE generation, cell state in registers;
 //   * waves 0-3 ("P waves") are the fused projection kernel at two row tiles per wave: wave w owns the 32 rows of row
 //     pair 4*rblk + w and the 80 columns of one vocabulary strip, W streamed from the packed image through a register
-//     ring whose first blocks are already in flight when h_t arrives.
+//     ring whose first blocks are already in flight when h_t arrives; they draw the Philox Gumbel noise of their own
+//     tile into an LDS slot of their own while the L waves run their phase (the matrix pipe is idle then).
 // Steps are chained by data flow, not by kernel boundaries: per row pair an arrival counter hc (the 32-row h_t is
 // published: NW arrivals per step) and pc (the strips of a step's projection are in `part`: nstrips arrivals per
 // step).  The recurrent product of step t+1 (which needs only h_t) runs on the L waves UNDER the projection of step
 // t; the critical path between two projections is poll -> merge of the strips -> table gather -> cell update ->
 // publish.  Hand-off protocol: common.h (sc1 payload stores, every storing wave drains, workgroup barrier, ONE lane
 // adds to the counter; consumers poll with sc1 loads and read the payload with sc1 loads only).  Every wave of a
-// workgroup executes the same five barriers per step whatever its role.  All waits are bounded (timeout word).
+// workgroup executes the same four barriers per step whatever its role.  All waits are bounded (timeout word).
+// Measured on MI355X (tools/gen_fwd_time.py): 54.5 us per step against 50.6 for the step launches -- what residency saves
+// (the 5 us weight fetch, the launch) the two in-launch hand-offs and the register pressure of two roles in one kernel
+// give back -- so this path is opt-in (gen_decode.PERSIST), kept as the measured alternative.
 #include "common.h"
 #include "gemm_stage.h"
 #include "pg_epilogue.h"

@@ -42,7 +42,8 @@ class GenBwdArgs(ctypes.Structure):          # a4nt_gen_bwd_args
                 ('stats', c_void_p), ('coef', c_float), ('inv_tau', c_float),
                 ('emb_W', c_void_p), ('W_out', c_void_p), ('ldw', c_int), ('Wcat', c_void_p),
                 ('gates', c_void_p), ('cs', c_void_p), ('dc', c_void_p), ('dG', c_void_p), ('rec', c_void_p),
-                ('dh_slabs', c_void_p), ('ks_v', c_int), ('rec_slabs', c_void_p), ('ks_r', c_int)]
+                ('dh_slabs', c_void_p), ('ks_v', c_int), ('rec_slabs', c_void_p), ('ks_r', c_int),
+                ('fold', c_void_p), ('abuf', c_void_p)]
 
 
 _SIGS = {
@@ -106,6 +107,7 @@ _SIGS = {
     'a4nt_colsum_ws_floats': (c_longlong, [c_int, c_int]),
     'a4nt_colsum': (c_int, [c_int, c_int, P, c_int, P, c_int, P, c_longlong, P]),
     'a4nt_slab_reduce': (c_int, [c_int, c_longlong, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, P]),
+    'a4nt_slab_reduce2': (c_int, [c_int, c_longlong, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int, P, c_int, P]),
     'a4nt_conv1d_tm': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_float, P, c_int, c_int,
                                c_int, c_int, c_int, P, P]),
     'a4nt_maxkey_init': (c_int, [c_int, c_int, P, c_int, P]),

@@ -61,7 +61,7 @@ extern "C" int a4nt_gen_loop_fwd(const a4nt_gen_fwd_args* a, int t0, int t1, voi
 extern "C" int a4nt_gen_loop_bwd(const a4nt_gen_bwd_args* a, void* stream) {
     if (!a || a->n <= 0 || a->B <= 0 || a->H <= 0 || a->E <= 0 || a->V <= 0 || !a->S || !a->D || !a->y || !a->stats ||
         !a->emb_W || !a->W_out || !a->Wcat || !a->gates || !a->cs || !a->dc || !a->dG || !a->rec || !a->dh_slabs ||
-        a->ks_v < 1 || a->ks_r < 1 || (a->ks_r > 1 && !a->rec_slabs)) {
+        a->ks_v < 1 || a->ks_r < 1 || (a->ks_r > 1 && !a->rec_slabs) || (a->fold && !a->abuf)) {
         a4nt_set_error("a4nt_gen_loop_bwd: bad arguments");
         return A4NT_ERR_ARG;
     }
@@ -72,8 +72,12 @@ extern "C" int a4nt_gen_loop_bwd(const a4nt_gen_bwd_args* a, void* stream) {
         float* D_t = a->D + (long long)t * B * a->ldd;
         const float* rec_next = t < n - 1 ? a->rec + (long long)(t + 1) * B * HE : nullptr;
         int rc;
-        if (rec_next) {        // S_t += d(emb_{t+1}) * E^T
-            rc = gemm_nt_auto(a->B, a->V, a->E, rec_next + H, (int)HE, a->emb_W, a->E, S_t, a->lds, 1, stream);
+        // S_t += (d(emb_{t+1}) + fold_t) * E^T: the sum is in abuf (written with rec_{t+1}); the last step has fold alone
+        const float* A_t = nullptr; int lda_t = 0;
+        if (a->fold) { A_t = rec_next ? a->abuf : a->fold + (long long)t * B * E; lda_t = (int)E; }
+        else if (rec_next) { A_t = rec_next + H; lda_t = (int)HE; }
+        if (A_t) {
+            rc = gemm_nt_auto(a->B, a->V, a->E, A_t, lda_t, a->emb_W, a->E, S_t, a->lds, 1, stream);
             if (rc != A4NT_OK) return rc;
         }
         rc = a4nt_gumbel_bwd(a->B, a->V, S_t, a->lds, a->y + (long long)t * B * a->ldy, a->ldy, a->stats + t * B * 2, a->coef,
@@ -92,7 +96,11 @@ extern "C" int a4nt_gen_loop_bwd(const a4nt_gen_bwd_args* a, void* stream) {
             rc = a4nt_sgemm(0, 0, a->B, (int)HE, 4 * a->H, a->dG + t * B * 4 * H, 4 * a->H, a->Wcat, (int)HE, a->rec_slabs, (int)HE,
                             nullptr, 0, a->ks_r, B * HE, stream);
             if (rc != A4NT_OK) return rc;
-            rc = a4nt_slab_reduce(a->ks_r, B * HE, a->B, (int)HE, a->rec_slabs, (int)HE, 0, nullptr, 0, rec_t, (int)HE, stream);
+            if (a->fold && t > 0)
+                rc = a4nt_slab_reduce2(a->ks_r, B * HE, a->B, (int)HE, a->rec_slabs, (int)HE, rec_t, (int)HE, (int)H,
+                                       a->fold + (long long)(t - 1) * B * E, (int)E, a->abuf, (int)E, stream);
+            else
+                rc = a4nt_slab_reduce(a->ks_r, B * HE, a->B, (int)HE, a->rec_slabs, (int)HE, 0, nullptr, 0, rec_t, (int)HE, stream);
         } else if (a->B <= 256 && HE >= 2048) {      // few rows x wide weight: the LDS-free kernel (as ops.gemm routes it)
             rc = a4nt_sgemm_skinny(0, a->B, (int)HE, 4 * a->H, a->dG + t * B * 4 * H, 4 * a->H, a->Wcat, (int)HE, rec_t, (int)HE,
                                    nullptr, 0, 1, 0, stream);
@@ -101,6 +109,11 @@ extern "C" int a4nt_gen_loop_bwd(const a4nt_gen_bwd_args* a, void* stream) {
                             0, 1, 0, stream);
         }
         if (rc != A4NT_OK) return rc;
+        if (a->fold && t > 0 && a->ks_r <= 1) {      // rec_t was written by the product itself: the sum takes a launch of its own
+            rc = a4nt_slab_reduce2(1, 0, a->B, (int)HE, rec_t, (int)HE, rec_t, (int)HE, (int)H,
+                                   a->fold + (long long)(t - 1) * B * E, (int)E, a->abuf, (int)E, stream);
+            if (rc != A4NT_OK) return rc;
+        }
     }
     return A4NT_OK;
 }

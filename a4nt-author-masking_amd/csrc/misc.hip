@@ -135,14 +135,17 @@ extern "C" int a4nt_colsum(int M, int N, const float* A, int lda, float* out, in
 }
 
 // out[r][c] = sum_s slabs[s*stride + r*lds + c0 + c] (+ add[r][c]),  r < R, c < C
+// optional second output (a4nt_slab_reduce2): out2[r][c - c2] = out[r][c] + add2[r][c - c2] for the columns c >= c2
+struct Slab2 { const float* add2; int lda2; float* out2; int ldo2; int c2; };
 __global__ void slab_reduce_kernel(int S, long long stride, int R, int C, const float* slabs, int lds, int c0,
-                                   const float* add, int lda, float* out, int ldo) {
+                                   const float* add, int lda, float* out, int ldo, Slab2 x) {
     const long long total = (long long)R * C;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / C), c = (int)(i - (long long)r * C);
         float v = add ? add[(long long)r * lda + c] : 0.f;
         for (int s = 0; s < S; ++s) v += slabs[s * stride + (long long)r * lds + c0 + c];
         out[(long long)r * ldo + c] = v;
+        if (x.out2 && c >= x.c2) x.out2[(long long)r * x.ldo2 + c - x.c2] = v + x.add2[(long long)r * x.lda2 + c - x.c2];
     }
 }
 // the same with 16-byte accesses (every row start and leading dimension 16-byte aligned, C a multiple of 4): the
@@ -150,7 +153,8 @@ __global__ void slab_reduce_kernel(int S, long long stride, int R, int C, const 
 // in flight instead of S dependent-looking 4-byte ones
 template <int SMAX>
 __global__ __launch_bounds__(256) void slab_reduce4_kernel(int S, long long stride, int R, int C4, const float* slabs,
-                                                           int lds, int c0, const float* add, int lda, float* out, int ldo) {
+                                                           int lds, int c0, const float* add, int lda, float* out, int ldo,
+                                                           Slab2 x) {
     const int total = R * C4;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int r = i / C4, c = 4 * (i - r * C4);
@@ -164,27 +168,44 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(int S, long long stri
         for (int s = 0; s < SMAX; ++s)
             if (s < S) { acc.x += v[s].x; acc.y += v[s].y; acc.z += v[s].z; acc.w += v[s].w; }
         *reinterpret_cast<f32x4*>(out + (long long)r * ldo + c) = acc;
+        if (x.out2 && c >= x.c2) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(x.add2 + (long long)r * x.lda2 + c - x.c2);
+            acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+            *reinterpret_cast<f32x4*>(x.out2 + (long long)r * x.ldo2 + c - x.c2) = acc;
+        }
     }
 }
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-extern "C" int a4nt_slab_reduce(int S, long long stride, int R, int C, const float* slabs, int lds, int c0,
-                                const float* add, int lda, float* out, int ldo, void* stream) {
+static int slab_reduce_launch(int S, long long stride, int R, int C, const float* slabs, int lds, int c0,
+                              const float* add, int lda, float* out, int ldo, Slab2 x, void* stream) {
     if (R <= 0 || C <= 0) return A4NT_OK;
     if (S < 1 || !slabs || !out) { a4nt_set_error("a4nt_slab_reduce: bad arguments"); return A4NT_ERR_ARG; }
     const long long total = (long long)R * C;
+    const bool x_ok = !x.out2 || ((x.lda2 & 3) == 0 && (x.ldo2 & 3) == 0 && (x.c2 & 3) == 0 && al16(x.add2) && al16(x.out2));
     if (S <= 16 && (C & 3) == 0 && (lds & 3) == 0 && (c0 & 3) == 0 && (ldo & 3) == 0 && (stride & 3) == 0 && al16(slabs) &&
-        al16(out) && (!add || ((lda & 3) == 0 && al16(add))) && total / 4 < 0x7fffffffll) {
+        al16(out) && (!add || ((lda & 3) == 0 && al16(add))) && x_ok && total / 4 < 0x7fffffffll) {
         const int n4 = (int)(total / 4);
         const int bs = n4 <= 65536 ? 64 : 256;          // small (per-step) reductions: one wave per workgroup, on every CU
         const int grid = min(2048, (n4 + bs - 1) / bs);
-        if (S <= 8) hipLaunchKernelGGL((slab_reduce4_kernel<8>), dim3(grid), dim3(bs), 0, (hipStream_t)stream, S, stride, R, C / 4, slabs, lds, c0, add, lda, out, ldo);
-        else hipLaunchKernelGGL((slab_reduce4_kernel<16>), dim3(grid), dim3(bs), 0, (hipStream_t)stream, S, stride, R, C / 4, slabs, lds, c0, add, lda, out, ldo);
+        if (S <= 8) hipLaunchKernelGGL((slab_reduce4_kernel<8>), dim3(grid), dim3(bs), 0, (hipStream_t)stream, S, stride, R, C / 4, slabs, lds, c0, add, lda, out, ldo, x);
+        else hipLaunchKernelGGL((slab_reduce4_kernel<16>), dim3(grid), dim3(bs), 0, (hipStream_t)stream, S, stride, R, C / 4, slabs, lds, c0, add, lda, out, ldo, x);
         return a4nt_check_launch("slab_reduce");
     }
     const int grid = (int)min((long long)1024, (total + 255) / 256);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, S, stride, R, C, slabs, lds, c0,
-                       add, lda, out, ldo);
+                       add, lda, out, ldo, x);
     return a4nt_check_launch("slab_reduce");
+}
+extern "C" int a4nt_slab_reduce(int S, long long stride, int R, int C, const float* slabs, int lds, int c0,
+                                const float* add, int lda, float* out, int ldo, void* stream) {
+    Slab2 x = {nullptr, 0, nullptr, 0, 0};
+    return slab_reduce_launch(S, stride, R, C, slabs, lds, c0, add, lda, out, ldo, x, stream);
+}
+extern "C" int a4nt_slab_reduce2(int S, long long stride, int R, int C, const float* slabs, int lds, float* out, int ldo,
+                                 int c2, const float* add2, int lda2, float* out2, int ldo2, void* stream) {
+    if (!add2 || !out2 || c2 < 0 || c2 > C) { a4nt_set_error("a4nt_slab_reduce2: bad arguments"); return A4NT_ERR_ARG; }
+    Slab2 x = {add2, lda2, out2, ldo2, c2};
+    return slab_reduce_launch(S, stride, R, C, slabs, lds, 0, nullptr, 0, out, ldo, x, stream);
 }
 
 // Element-wise LSTM cell backward of one decoder step:

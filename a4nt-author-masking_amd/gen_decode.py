@@ -31,6 +31,7 @@ _LOOP_LABELS = ('proj_gumbel', 'sgemm_nt_64', 'sgemm_nn_64', 'sgemm_nt_rows', 's
 
 
 PY_LOOPS = False          # benchmarks: drive the loops from Python even when nothing is being timed
+FOLD_SAME_EMBEDDING = True   # backward: see _GenDecode.backward (False: every consumer contracted time-batched, as in r02)
 # The forward loop as one persistent launch (a4nt_gen_persist_fwd, csrc/genpersist.hip).  False (default): the per-step
 # launches -- measured on the box (tools/gen_fwd_time.py, 256 rows, H = 512, V = 10001): 54.5 us per step for the
 # persistent launch against 50.6 for the two launches per step; DESIGN.md section 7a has the phase stamps.  True:
@@ -364,6 +365,18 @@ class _GenDecode(Function):
         S = S2.unflatten(0, (n, B))
         first = True
         contribs = [(demb[:n].reshape(n * B, -1), W) for demb, W in handle.contribs]
+        # Consumers that embedded the samples with THIS decoder's embedding matrix (the reconstruction encoder): their
+        # d(embedding) joins the decoder's own d(embedding input of step t+1) before the contraction with emb_W^T in the
+        # reverse loop -- (a + b) E^T instead of a E^T + b E^T -- so the time-batched [n*B, V] x K product below loses
+        # their K columns (131 GFLOP of 262 at cfg 3).  Not with the GradFilter, which looks at S before the loop.
+        fold = None
+        if FOLD_SAME_EMBEDDING and not handle.grad_filter:
+            same = [d for d, W in contribs if W.data_ptr() == emb_W.data_ptr() and W.shape == emb_W.shape and W.is_contiguous()]
+            if same:
+                contribs = [(d, W) for d, W in contribs if not (W.data_ptr() == emb_W.data_ptr() and W.shape == emb_W.shape
+                                                                  and W.is_contiguous())]
+                fold = same[0] if len(same) == 1 else torch.stack(same).sum(0)
+                fold = fold.contiguous().view(n, B, E)
         if len(contribs) > 1 and all(W.shape[0] == V for _, W in contribs):
             # sum_i demb_i W_i^T = [demb_1 | demb_2 | ..] [W_1 | W_2 | ..]^T: one product over the concatenated
             # embedding dimensions instead of one per consumer, each re-reading and re-writing the [n*B, V] buffer
@@ -410,10 +423,14 @@ class _GenDecode(Function):
             ba.emb_W, ba.W_out, ba.ldw, ba.Wcat = ops._p(emb_c), ops._p(Wo_c), ops._ld(Wo_c), ops._p(Wcat)
             ba.gates, ba.cs, ba.dc, ba.dG, ba.rec = ops._p(gates), ops._p(cs), ops._p(dc), ops._p(dG), ops._p(rec)
             ba.dh_slabs, ba.ks_v, ba.rec_slabs, ba.ks_r = ops._p(dh_slabs), ks_v, ops._p(rec_slabs), ks_r
+            abuf = torch.empty((B, E), device=dev) if fold is not None else None
+            ba.fold, ba.abuf = ops._p(fold), ops._p(abuf)
             _lib.check(lib.a4nt_gen_loop_bwd(ctypes.byref(ba), s), 'a4nt_gen_loop_bwd')
         else:
             for t in range(n - 1, -1, -1):
-                if t < n - 1:
+                if fold is not None:
+                    gemm(fold[t] if t == n - 1 else rec[t + 1][:, H:] + fold[t], emb_W, transB=True, out=S[t], beta=1)
+                elif t < n - 1:
                     gemm(rec[t + 1][:, H:], emb_W, transB=True, out=S[t], beta=1)      # += d(emb_{t+1}) * E^T
                 ops.gumbel_bwd_rows(S[t], ybuf[t], stats[t], coef, 1.0 / float(cfg['tau']), out=D[t])   # dlogits_t
                 gemm(D[t], W_out, transB=True, out=dh_slabs if ks_v > 1 else dh_slabs[0], ksplit=ks_v)

@@ -210,6 +210,10 @@ typedef struct {
     const float* emb_W; const float* W_out; int ldw; const float* Wcat;
     const float* gates; const float* cs; float* dc; float* dG; float* rec;
     float* dh_slabs; int ks_v; float* rec_slabs; int ks_r;
+    /* consumers of the samples that embedded them with emb_W itself (the reconstruction encoder): their d(embedding)
+     * [n][B][E], summed, joins d(emb input of step t+1) BEFORE the contraction with emb_W^T instead of being contracted
+     * on its own, time-batched (S_t += (rec_{t+1}[:, H:] + fold_t) emb_W^T); NULL = none.  abuf: [B][E] scratch. */
+    const float* fold; float* abuf;
 } a4nt_gen_bwd_args;
 int a4nt_gen_loop_fwd(const a4nt_gen_fwd_args* a, int t0, int t1, void* stream);
 int a4nt_gen_loop_bwd(const a4nt_gen_bwd_args* a, void* stream);
@@ -346,6 +350,10 @@ int a4nt_colsum(int M, int N, const float* A, int lda, float* out, int accumulat
 /* out[r][c] = sum_s slabs[s*stride + r*lds + c0 + c] (+ add[r][c])  (split-K reduction). */
 int a4nt_slab_reduce(int S, long long stride, int R, int C, const float* slabs, int lds, int c0, const float* add,
                      int lda, float* out, int ldo, void* stream);
+/* The same reduction with a second output: out2[r][c - c2] = out[r][c] + add2[r][c - c2] for the columns c >= c2 (the
+ * reverse loop of the generator: rec_t and, in the same launch, the A operand of the next d(sample) product). */
+int a4nt_slab_reduce2(int S, long long stride, int R, int C, const float* slabs, int lds, float* out, int ldo, int c2,
+                      const float* add2, int lda2, float* out2, int ldo2, void* stream);
 
 /* Conv1d over time-major activations, all K taps accumulated in the MFMA accumulators of one launch, with bias,
  * leaky_relu, placement into a (zero-padded / cropped, concatenated) output and the max over time in the epilogue.

@@ -22,6 +22,7 @@
 // Sequences of different lengths: a row simply freezes (state kept, output zero, gradient zero)
 // once t >= len[row]; no sorting or packing is needed by the kernels.
 #include "common.h"
+#include <atomic>
 
 // Diagnostic build only (-DA4NT_STAMP, tools/lstm_stamp.py): per-phase s_memtime sums of workgroup 0,
 // written to spare words of the sync block that no kernel code reads.  Never defined in the product.
@@ -1183,12 +1184,13 @@ extern "C" int a4nt_lstm_seq_fwd(int T, int B, int H, const float* gx, const flo
 #define A4NT_SCRATCH_BYTES (A4NT_SCRATCH_XCH_FLOATS * 4 + A4NT_SCRATCH_SYNC_WORDS * 4)
 static __device__ __align__(256) unsigned char scratch[A4NT_SCRATCH_BYTES];
 // device address of `scratch` per device (the name itself is a host-side stand-in, never a kernel argument)
-static void* g_scratch_ptr[A4NT_MAX_DEV];
+// (atomic: two host threads may look the same device up at once; both get the same address)
+static std::atomic<void*> g_scratch_ptr[A4NT_MAX_DEV];
 
 // `device` must be current.  Called by a4nt_init; the entry point repeats it for a device that was never initialised.
 static int scratch_lookup(int device) {
     if (device < 0 || device >= A4NT_MAX_DEV) { a4nt_set_error("a4nt: device index %d beyond the %d this library tracks", device, A4NT_MAX_DEV); return A4NT_ERR_ARG; }
-    if (g_scratch_ptr[device]) return A4NT_OK;
+    if (g_scratch_ptr[device].load(std::memory_order_acquire)) return A4NT_OK;
     void* ptr = nullptr;
     const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !ptr) {
@@ -1196,7 +1198,7 @@ static int scratch_lookup(int device) {
         (void)hipGetLastError();
         return A4NT_ERR_LAUNCH;
     }
-    g_scratch_ptr[device] = ptr;
+    g_scratch_ptr[device].store(ptr, std::memory_order_release);
     return A4NT_OK;
 }
 
@@ -1216,7 +1218,7 @@ extern "C" int a4nt_lstm_seq_fwd_noalloc(int T, int B, int H, const float* gx, c
     if (hipGetDevice(&dev) != hipSuccess) return a4nt_check_launch("a4nt_lstm_seq_fwd_noalloc: hipGetDevice");
     rc = scratch_lookup(dev);
     if (rc != A4NT_OK) return rc;
-    unsigned char* base = (unsigned char*)g_scratch_ptr[dev];      // the looked-up device address, never `scratch`
+    unsigned char* base = (unsigned char*)g_scratch_ptr[dev].load(std::memory_order_acquire);      // the looked-up device address, never `scratch`
     float* xch = (float*)base;
     unsigned* sync = (unsigned*)(base + (size_t)A4NT_SCRATCH_XCH_FLOATS * 4);
     unsigned* tmo = timeout_word ? timeout_word : sync + (A4NT_SCRATCH_SYNC_WORDS - 32);

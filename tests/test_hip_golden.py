@@ -158,3 +158,47 @@ def test_fused_update_matches_separate_updates(impl, name):
     for (n1, p1), (_, p2) in zip(G1.named_parameters(), G2.named_parameters()):
         assert_close(p2.grad, p1.grad, TOL_GRAD, name + ' G grad ' + n1)
         assert_close(p2, p1, TOL_OUT, name + ' G weight ' + n1)
+
+
+@pytest.mark.parametrize('name', sc.ADV_STEP)
+@pytest.mark.parametrize('py_loops', [False, True])
+def test_folded_sample_gradient_matches_time_batched(impl, name, py_loops):
+    """Generator update with the reconstruction encoder's d(embedding) folded into the reverse loop's own product
+    ((a + b) E^T, gen_decode.FOLD_SAME_EMBEDDING, the default) against every consumer contracted time-batched
+    (a E^T + b E^T, the r02 arithmetic): same losses and tokens, gradients to the parity tolerance; with the library's
+    C++ loop and with the Python per-step loop."""
+    from golden_util import Fixture, assert_close
+    from a4nt_amd import gen_decode
+    fx = Fixture(name)
+    ep = fx.json('eval_params_json')
+    B = fx.t('gb.inps').shape[1]
+    c_aid = int(fx.scalar('c_aid'))
+    end_c, maxlen, temp = int(fx.scalar('end_c')), int(fx.scalar('maxlen')), float(fx.scalar('temp'))
+    gb = (fx.t('gb.inps'), fx.t('gb.targs'), torch.LongTensor([c_aid] * B), fx.np('gb.lens').tolist())
+    noise = fx.noise_list('cuda')[int(fx.scalar('n_noise_d')):]
+    append = torch.zeros(1, B, fx.params['vocabulary_size'] + 1, device='cuda')
+    append[:, :, 2] = 1.0
+    res = []
+    for fold in (False, True):
+        G = impl.CharTranslator(fx.params)
+        G.load_state_dict({k: v.cuda() for k, v in fx.group('sdG0.').items()})
+        E = impl.CharLstm(ep) if ep.get('modeltype', 'lstm') == 'lstm' else impl.CharCNN(ep)
+        E.load_state_dict({k: v.cuda() for k, v in fx.group('sdE0.').items()})
+        G.train(), E.train()
+        oG, _ = impl.make_optimizers(G, E)
+        G.set_noise([u.clone() for u in noise])
+        gen_decode.FOLD_SAME_EMBEDDING, gen_decode.PY_LOOPS = fold, py_loops
+        try:
+            rg = impl.g_update(G, E, oG, gb, c_aid, end_c, maxlen, temp, append, cycle_loss_type='ml', step=False)
+        finally:
+            gen_decode.FOLD_SAME_EMBEDDING, gen_decode.PY_LOOPS = True, False
+        res.append((rg, {n: p.grad.clone() for n, p in G.named_parameters() if p.grad is not None}))
+    impl.check_timeouts()
+    (r0, g0), (r1, g1) = res
+    assert torch.equal(torch.stack(list(r0['char_outs'])), torch.stack(list(r1['char_outs'])))
+    for k in ('loss', 'loss_gan', 'cyc_loss'):
+        assert_close(r1[k], r0[k], TOL_OUT, name + ' ' + k)
+    assert_close(r1['grad_norm'], r0['grad_norm'], TOL_GRAD, name + ' grad norm')
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert_close(g1[n], g0[n], TOL_GRAD, name + ' grad ' + n)

@@ -20,7 +20,7 @@ class LstmFwdProblem(ctypes.Structure):      # a4nt_lstm_fwd_problem
 
 class LstmBwdProblem(ctypes.Structure):      # a4nt_lstm_bwd_problem
     _fields_ = [('T', c_int), ('B', c_int)] + [(n, c_void_p) for n in (
-        'whh', 'gates', 'cs', 'c0', 'lens', 'dhs', 'dhN', 'dcN', 'dgates', 'dh0', 'dc0', 'xch', 'sync')]
+        'whh', 'gates', 'cs', 'c0', 'lens', 'dhs', 'dhN', 'dcN', 'dgates', 'dh0', 'dc0', 'xch', 'sync', 'dbias')]
 
 
 class GenFwdArgs(ctypes.Structure):          # a4nt_gen_fwd_args
@@ -66,6 +66,8 @@ _SIGS = {
     'a4nt_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'a4nt_lstm_seq_fwd_noalloc': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'a4nt_lstm_seq_bwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'a4nt_lstm_bwd_bias_rows': (c_int, [c_int, c_int]),
+    'a4nt_lstm_seq_bwd_bias': (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'a4nt_lstm_pair_geometry': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'a4nt_lstm_pair_xch_floats': (c_longlong, [c_int, c_int, c_int, c_int]),
     'a4nt_lstm_pair_sync_words': (c_int, [c_int, c_int]),

@@ -419,6 +419,7 @@ struct LstmBwdArgs {
     unsigned* sync;
     unsigned* tmo;
     int need_dh0;           // run the recurrent product of the last step too
+    float* dbias;           // [G][4H] per-row-group column sums of dgates (the bias gradient's partials) or null; 2-D kernels only
 };
 
 template <int MT, int NJ>
@@ -811,11 +812,15 @@ __device__ __forceinline__ void lstm_bwdx_body(const LstmBwdArgs& a, const int b
         }
     }
 
+    // (rows past the batch or past their length hold zeros in the tile: the running column sum takes every row)
+    float bsum = 0.f;
     auto store_dgates = [&](const int t, const int m) {
         for (int idx = tid; idx < 16 * 64; idx += 256) {
             const int row = idx >> 6, cc = idx & 63;
+            const float v = sA[row * SA + q * 64 + cc];
+            bsum += v;
             if (r0 + 16 * m + row < a.B)
-                a.dgates[((long long)t * a.B + r0 + 16 * m + row) * H4 + q * H + u0 + cc] = sA[row * SA + q * 64 + cc];
+                a.dgates[((long long)t * a.B + r0 + 16 * m + row) * H4 + q * H + u0 + cc] = v;
         }
     };
 
@@ -922,6 +927,14 @@ __device__ __forceinline__ void lstm_bwdx_body(const LstmBwdArgs& a, const int b
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the wave (early exits included)
 
+    if (a.dbias) {
+        // bias gradient of this row group: the four waves hold the sums of rows w, w+4, .. of the same 64 columns
+        __syncthreads();
+        sA[tid] = bsum;
+        __syncthreads();
+        if (tid < 64)
+            a.dbias[(long long)g * H4 + q * H + u0 + tid] = (sA[tid] + sA[64 + tid]) + (sA[128 + tid] + sA[192 + tid]);
+    }
     if (q == 0) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1289,10 +1302,32 @@ extern "C" int a4nt_lstm_dec_step_merge(int step, int B, int H, const float* cg,
                            xch, f, stream);
 }
 
+static int seq_bwd(int T, int B, int H, const float* whh, const float* gates, const float* cs,
+                   const float* c0, const int* lens, const float* dhs, const float* dhN,
+                   const float* dcN, float* dgates, float* dh0, float* dc0, float* dbias, float* xch, unsigned* sync,
+                   void* stream);
 extern "C" int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const float* gates, const float* cs,
                                  const float* c0, const int* lens, const float* dhs, const float* dhN,
                                  const float* dcN, float* dgates, float* dh0, float* dc0, float* xch, unsigned* sync,
                                  void* stream) {
+    return seq_bwd(T, B, H, whh, gates, cs, c0, lens, dhs, dhN, dcN, dgates, dh0, dc0, nullptr, xch, sync, stream);
+}
+extern "C" int a4nt_lstm_bwd_bias_rows(int B, int H) {
+    int mt, G;
+    if (H < 256 || a4nt_lstm_geometry(B, H, &mt, &G) != A4NT_OK) return 0;
+    return G;
+}
+extern "C" int a4nt_lstm_seq_bwd_bias(int T, int B, int H, const float* whh, const float* gates, const float* cs,
+                                      const float* c0, const int* lens, const float* dhs, const float* dhN,
+                                      const float* dcN, float* dgates, float* dh0, float* dc0, float* dbias_part,
+                                      float* xch, unsigned* sync, void* stream) {
+    if (dbias_part && H < 256) { a4nt_set_error("a4nt_lstm_seq_bwd_bias: bias partials need H >= 256 (a4nt_lstm_bwd_bias_rows)"); return A4NT_ERR_ARG; }
+    return seq_bwd(T, B, H, whh, gates, cs, c0, lens, dhs, dhN, dcN, dgates, dh0, dc0, dbias_part, xch, sync, stream);
+}
+static int seq_bwd(int T, int B, int H, const float* whh, const float* gates, const float* cs,
+                   const float* c0, const int* lens, const float* dhs, const float* dhN,
+                   const float* dcN, float* dgates, float* dh0, float* dc0, float* dbias, float* xch, unsigned* sync,
+                   void* stream) {
     int mt, G;
     int rc = a4nt_lstm_geometry(B, H, &mt, &G);
     if (rc != A4NT_OK) return rc;
@@ -1307,6 +1342,7 @@ extern "C" int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const fl
     a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens; a.dhs = dhs; a.dhN = dhN; a.dcN = dcN;
     a.dgates = dgates; a.dh0 = dh0; a.dc0 = dc0; a.gxch = xch; a.sync = sync; a.tmo = sync + 32 * G;
     a.need_dh0 = (dh0 != nullptr) ? 1 : 0;
+    a.dbias = dbias;
     dim3 grid(G * a.NW), block(256);
     if (H >= 256) {
         if (bwdx_misaligned(a)) { a4nt_set_error("a4nt_lstm_seq_bwd: gates / cs / c0 / dhs must be 16-byte aligned at H >= 256"); return A4NT_ERR_ARG; }
@@ -1410,6 +1446,7 @@ extern "C" int a4nt_lstm_seq_bwd_pair(int H, const a4nt_lstm_bwd_problem* p0, co
         q.dhs = p[i]->dhs; q.dhN = p[i]->dhN; q.dcN = p[i]->dcN;
         q.dgates = p[i]->dgates; q.dh0 = p[i]->dh0; q.dc0 = p[i]->dc0; q.gxch = p[i]->xch; q.sync = p[i]->sync; q.tmo = p[i]->sync + 32 * G[i];
         q.need_dh0 = (p[i]->dh0 != nullptr) ? 1 : 0;
+        q.dbias = H >= 256 ? p[i]->dbias : nullptr;
     }
     const int nA = G[0] * (H / 16);
     dim3 grid((G[0] + G[1]) * (H / 16)), block(256);

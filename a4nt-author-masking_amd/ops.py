@@ -410,11 +410,23 @@ def lstm_seq_bwd(w_hh, gates, cs, c0, lens_dev, dhs, dhN, dcN, need_h0):
     dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
     dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
     with _bwd_budget():
-        xch, sync, _ = _lstm_ws(dev, B, H, True)
+        xch, sync, g = _lstm_ws(dev, B, H, True)
+        # H >= 256: the sweep leaves the bias gradient's per-row-group partial sums (no pass over dgates for them)
+        dbp = torch.empty((g, H4), device=dev, dtype=torch.float32) if H >= 256 else None
         with _Timed('lstm_seq_bwd', 8.0 * T * B * H * H):
-            check(lib.a4nt_lstm_seq_bwd(T, B, H, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN),
-                                        _p(dcN), _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync), _s()), 'a4nt_lstm_seq_bwd')
+            check(lib.a4nt_lstm_seq_bwd_bias(T, B, H, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN),
+                                             _p(dcN), _p(dgates), _p(dh0), _p(dc0), _p(dbp), _p(xch), _p(sync), _s()),
+                  'a4nt_lstm_seq_bwd_bias')
+    dgates._a4nt_dbias = dbp
     return dgates, dh0, dc0
+
+
+def lstm_bias_grad(dgates):
+    """d(b_ih) = d(b_hh) = column sums of dgates [T,B,4H]: from the partials the backward sweep left, else a pass."""
+    part = getattr(dgates, '_a4nt_dbias', None)
+    if part is not None:
+        return part.sum(0)
+    return colsum(dgates.view(-1, dgates.shape[-1]))
 
 
 def lstm_pair_geometry(B0, B1, H):
@@ -492,8 +504,10 @@ def lstm_seq_bwd_pair(reqs):
                 dgates = torch.empty_like(gates)
                 dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
                 dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if need_h0 else None
+                dbp = torch.empty((_g, 4 * H), device=dev, dtype=torch.float32) if H >= 256 else None
                 probs.append(_lib.LstmBwdProblem(T, B, _p(w_hh), _p(gates), _p(cs), _p(c0), _p(lens_dev), _p(dhs), _p(dhN),
-                                                 _p(dcN), _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync)))
+                                                 _p(dcN), _p(dgates), _p(dh0), _p(dc0), _p(xch), _p(sync), _p(dbp)))
+                dgates._a4nt_dbias = dbp
                 outs.append((dgates, dh0, dc0))
                 flops += 8.0 * T * B * H * H
             with _Timed('lstm_seq_bwd', flops):
@@ -583,7 +597,7 @@ class _LstmLayer(Function):
         dx = gemm_auto(dG2, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = gemm_auto(dG2, x2, transA=True) if ctx.needs_input_grad[1] else None
         dw_hh = gemm_auto(dG2, hs_all[:T].view(T * B, H), transA=True) if ctx.needs_input_grad[2] else None
-        db = colsum(dG2) if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
+        db = lstm_bias_grad(dgates) if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
         dgc = colsum(dgates.view(T, B * 4 * H)).view(B, 4 * H) if (has_gc and ctx.needs_input_grad[7]) else None
         return dx, dw_ih, dw_hh, db, db, (dh0 if has_h0 else None), (dc0 if has_c0 else None), dgc, None
 
@@ -747,7 +761,7 @@ class _LstmLayerPair(Function):
             dx = gemm_auto(dG2, w_ih).view(T, B, I) if nig[0] else None
             dw_ih = gemm_auto(dG2, x2, transA=True) if nig[1] else None
             dw_hh = gemm_auto(dG2, hs_all[:T].view(T * B, H), transA=True) if nig[2] else None
-            db = colsum(dG2) if (nig[3] or nig[4]) else None
+            db = lstm_bias_grad(dgates) if (nig[3] or nig[4]) else None
             dgc = colsum(dgates.view(T, B * 4 * H)).view(B, 4 * H) if (has_gc and nig[7]) else None
             grads += [dx, dw_ih, dw_hh, db, db, (dh0 if has_h0 else None), (dc0 if has_c0 else None), dgc, None]
         return tuple(grads)

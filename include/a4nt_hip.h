@@ -128,6 +128,16 @@ int a4nt_lstm_seq_fwd_noalloc(int T, int B, int H, const float* gx, const float*
 int a4nt_lstm_seq_bwd(int T, int B, int H, const float* whh, const float* gates, const float* cs, const float* c0,
                       const int* lens, const float* dhs, const float* dhN, const float* dcN, float* dgates,
                       float* dh0, float* dc0, float* xch, unsigned* sync, void* stream);
+/* The same sweep that also leaves the bias gradient's partial sums: dbias_part [a4nt_lstm_bwd_bias_rows(B, H)][4H] =
+ * per row group, the column sums of dgates over all steps and the group's rows (the caller adds the few rows: that IS
+ * d(b_ih) = d(b_hh)), accumulated from the dgates tiles while they are in LDS -- no pass over the [T*B, 4H] matrix.
+ * H >= 256 (the 2-D sweep kernels); a4nt_lstm_bwd_bias_rows returns 0 where the partials are not available.
+ * Replaces: the bias part of nn.LSTM's BPTT (models/char_translator.py:182-197, models/char_lstm.py:148-163). */
+int a4nt_lstm_bwd_bias_rows(int B, int H);
+int a4nt_lstm_seq_bwd_bias(int T, int B, int H, const float* whh, const float* gates, const float* cs,
+                           const float* c0, const int* lens, const float* dhs, const float* dhN, const float* dcN,
+                           float* dgates, float* dh0, float* dc0, float* dbias_part, float* xch, unsigned* sync,
+                           void* stream);
 
 /* Two independent sweeps in ONE launch: workgroups of both problems are co-resident, so one sweep's MFMA
  * phase runs under the other's hand-off waits (two 128-row sweeps at H = 512 each fill half of the 512
@@ -148,6 +158,7 @@ typedef struct {
     const float* whh; const float* gates; const float* cs; const float* c0; const int* lens;
     const float* dhs; const float* dhN; const float* dcN;
     float* dgates; float* dh0; float* dc0; float* xch; unsigned* sync;
+    float* dbias;       /* [groups of this problem][4H] bias-gradient partials (H >= 256) or NULL: a4nt_lstm_seq_bwd_bias */
 } a4nt_lstm_bwd_problem;
 int a4nt_lstm_pair_geometry(int B0, int B1, int H, int* mt_out, int* g0_out, int* g1_out);
 long long a4nt_lstm_pair_xch_floats(int B, int H, int mt, int backward);

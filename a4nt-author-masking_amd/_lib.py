@@ -108,6 +108,7 @@ _SIGS = {
     'a4nt_embed_bwd': (c_int, [c_longlong, c_int, c_int, P, P, P, c_int, P, c_longlong, P]),
     'a4nt_colsum_ws_floats': (c_longlong, [c_int, c_int]),
     'a4nt_colsum': (c_int, [c_int, c_int, P, c_int, P, c_int, P, c_longlong, P]),
+    'a4nt_sgemm_tn_colsum': (c_int, [c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_longlong, P, P]),
     'a4nt_slab_reduce': (c_int, [c_int, c_longlong, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, P]),
     'a4nt_slab_reduce2': (c_int, [c_int, c_longlong, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int, P, c_int, P]),
     'a4nt_conv1d_tm': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_float, P, c_int, c_int,

@@ -36,6 +36,7 @@ struct GemmArgs {
     int tiles_n;
     float* part;         // NLL epilogue: [M][nparts][2] per-row (max, sum exp) over each wave's 64 columns, or null
     int nparts;
+    float* colpart;      // CS instantiation: [gridDim.z][N] column sums of B over this K slab (bias gradient), or null
 };
 
 #include "gemm_stage.h"
@@ -54,11 +55,21 @@ __device__ __forceinline__ void mma_tile(const float* as, const float* bs, int l
 // [kbeg, kend) is this k-group's range (possibly empty); nk and partial are workgroup-uniform: the loop
 // trip count (the largest group's full tiles) and whether some group has a partial last tile -- every
 // group runs the same barriers, a group with less work multiplies zeros.
-template <bool TA, bool TB, int WM, int WN, int PF, bool EA, bool EB>
+// CS (B stored [K][N] only): every staged B tile is also added, per thread, into colacc -- the thread's four columns
+// (tid % 32) * 4 .. + 3 of the tile, over the k rows it stages -- for the column sums of B (sgemm_kernel's CS epilogue).
+template <bool TA, bool TB, int WM, int WN, int PF, bool EA, bool EB, bool CS = false>
 __device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kbeg, int kend, int nk, bool partial,
                                        float (*As)[BK * (64 * WM + LPAD)],
                                        float (*Bs)[BK * (64 * WN + LPAD)], int lane, int wm, int wn,
-                                       f32x16 (&acc)[WM][WN]) {
+                                       f32x16 (&acc)[WM][WN], f32x4& colacc) {
+    auto cs_add = [&](const typename StageSel<!TB, 64 * WN>::type& st) {
+        if (CS) {
+#pragma unroll
+            for (int p = 0; p < StageSel<!TB, 64 * WN>::type::NV; ++p) {
+                colacc.x += st.v[p].x; colacc.y += st.v[p].y; colacc.z += st.v[p].z; colacc.w += st.v[p].w;
+            }
+        }
+    };
     constexpr int BM = 64 * WM, BN = 64 * WN;
     typename StageSel<TA, BM>::type sa[PF];      // TA: A stored [K][M] -> mn contiguous
     typename StageSel<!TB, BN>::type sb[PF];     // !TB: B stored [K][N] -> mn contiguous
@@ -71,6 +82,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kb
     if (nk > 0) {
         sa[0].store(As[0]);
         sb[0].store(Bs[0]);
+        cs_add(sb[0]);
     }
     __syncthreads();
     for (int kt0 = 0; kt0 < nk; kt0 += PF) {
@@ -85,6 +97,7 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kb
             mma_tile<WM, WN>(As[cur], Bs[cur], lane, wm, wn, acc);
             sa[(u + 1) % PF].store(As[cur ^ 1]);       // tile kt+1 (zeros when past the end)
             sb[(u + 1) % PF].store(Bs[cur ^ 1]);
+            cs_add(sb[(u + 1) % PF]);
             __syncthreads();
         }
     }
@@ -93,13 +106,15 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kb
         sb[0].template load<true>(g.B, g.ldb, n0, g.N, kfull, kend);
         sa[0].store(As[0]);
         sb[0].store(Bs[0]);
+        cs_add(sb[0]);
         __syncthreads();
         mma_tile<WM, WN>(As[0], Bs[0], lane, wm, wn, acc);
     }
 }
 
-template <bool TA, bool TB, int WM, int WN, int PF, int KG, bool NLL = false>
+template <bool TA, bool TB, int WM, int WN, int PF, int KG, bool NLL = false, bool CS = false>
 __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
+    static_assert(!CS || (!TB && KG == 1 && WN == 2), "column sums: B stored [K][N], 128-wide tiles");
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int ASZ = BK * (BM + LPAD), BSZ = BK * (BN + LPAD);
     static_assert(KG == 1 || (WM == 1 && WN == 1), "k-groups: 64x64 tiles only");
@@ -159,10 +174,26 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
     // workgroup-uniform edge flags of the "mn contiguous" operands (K-contiguous ones need none)
     const bool ea = TA && (g.M - m0 < BM);
     const bool eb = !TB && (g.N - n0 < BN);
-    if (!ea && !eb) k_loop<TA, TB, WM, WN, PF, false, false>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc);
-    else if (ea && !eb) k_loop<TA, TB, WM, WN, PF, true, false>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc);
-    else if (!ea && eb) k_loop<TA, TB, WM, WN, PF, false, true>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc);
-    else k_loop<TA, TB, WM, WN, PF, true, true>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc);
+    f32x4 colacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!ea && !eb) k_loop<TA, TB, WM, WN, PF, false, false, CS>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc, colacc);
+    else if (ea && !eb) k_loop<TA, TB, WM, WN, PF, true, false, CS>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc, colacc);
+    else if (!ea && eb) k_loop<TA, TB, WM, WN, PF, false, true, CS>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc, colacc);
+    else k_loop<TA, TB, WM, WN, PF, true, true, CS>(g, m0, n0, kbeg, kend, nk, partial, As, Bs, lane, wm, wn, acc, colacc);
+
+    if (CS) {
+        // column sums of B over this workgroup's K slab: the 8 threads that stage the same four columns (tid % 32) hold
+        // the k rows tid / 32, tid / 32 + 8, ...; summed through LDS in a fixed order; written by the first tile row only
+        __syncthreads();                               // the staging buffers are free
+        float* red = smem;                             // [8][128]
+        *reinterpret_cast<f32x4*>(&red[(threadIdx.x >> 5) * 128 + (threadIdx.x & 31) * 4]) = colacc;
+        __syncthreads();
+        if (tm == 0 && threadIdx.x < 128 && n0 + (int)threadIdx.x < g.N) {
+            const float* r = red + threadIdx.x;
+            g.colpart[(long long)zz * g.N + n0 + threadIdx.x] =
+                ((r[0] + r[128]) + (r[256] + r[384])) + ((r[512] + r[640]) + (r[768] + r[896]));
+        }
+        __syncthreads();
+    }
 
     if (KG > 1) {                                      // sum the k-groups' accumulators into group 0
         __syncthreads();                               // every group is done with its staging buffers
@@ -337,7 +368,7 @@ extern "C" int a4nt_sgemm(int transA, int transB, int M, int N, int K, const flo
     g.kchunk = kchunk;
     g.slab = slab_stride;
     g.tiles_n = 0;
-    g.part = nullptr; g.nparts = 0;
+    g.part = nullptr; g.nparts = 0; g.colpart = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const bool big = a4nt_sgemm_tile(M, N, ksplit) == 128;
     if (!transA && !transB) return big ? launch_sgemm<false, false, 2, 2, PFB>(g, ksplit, s) : launch_small<false, false>(g, ksplit, s);
@@ -359,11 +390,38 @@ extern "C" int a4nt_sgemm_nll(int M, int N, int K, const float* A, int lda, cons
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.beta = 0;
     g.kchunk = ((K + BK - 1) / BK) * BK;
     g.slab = 0;
-    g.part = part; g.nparts = a4nt_sgemm_nll_parts(N);
+    g.part = part; g.nparts = a4nt_sgemm_nll_parts(N); g.colpart = nullptr;
     constexpr int BM = 128, BN = 128;
     const int tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
     hipLaunchKernelGGL((sgemm_kernel<false, false, 2, 2, PFB, 1, true>), dim3(tiles_m * g.tiles_n, 1, 1), dim3(256), 0,
                        (hipStream_t)stream, g);
     return a4nt_check_launch("sgemm_nll");
+}
+
+// Weight gradient and bias gradient of a linear layer in one pass (include/a4nt_hip.h): C = A^T B and, from the B tiles
+// as they are staged, the column sums of B.
+extern "C" int a4nt_sgemm_tn_colsum(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                    int ksplit, long long slab_stride, float* colpart, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || !colpart || ksplit < 1 || lda < M || ldb < N ||
+        (ksplit > 1 && slab_stride < (long long)M * ldc)) {
+        a4nt_set_error("a4nt_sgemm_tn_colsum: bad arguments (M=%d N=%d K=%d ksplit=%d)", M, N, K, ksplit);
+        return A4NT_ERR_ARG;
+    }
+    if (a4nt_sgemm_tile(M, N, ksplit) != 128) {
+        a4nt_set_error("a4nt_sgemm_tn_colsum: %d x %d output in %d slabs is a few-tile product (a4nt_sgemm + a4nt_colsum)", M, N, ksplit);
+        return A4NT_ERR_ARG;
+    }
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.beta = 0;
+    int kchunk = (K + ksplit - 1) / ksplit;
+    g.kchunk = ((kchunk + BK - 1) / BK) * BK;
+    g.slab = slab_stride;
+    g.part = nullptr; g.nparts = 0; g.colpart = colpart;
+    const int tiles_m = (M + 127) / 128;
+    g.tiles_n = (N + 127) / 128;
+    hipLaunchKernelGGL((sgemm_kernel<true, false, 2, 2, PFB, 1, false, true>), dim3(tiles_m * g.tiles_n, 1, ksplit), dim3(256), 0,
+                       (hipStream_t)stream, g);
+    return a4nt_check_launch("sgemm_tn_colsum");
 }

@@ -447,8 +447,7 @@ class _GenDecode(Function):
                     gemm(dG[t], Wcat, out=rec[t])
         demb_all = rec[:, :, H:].contiguous()
         dG2 = dG.view(n * B, 4 * H)
-        d_W_out = gemm_auto(hs_all[1:n + 1].reshape(n * B, H), D2, transA=True)
-        d_b_out = colsum(D2)
+        d_W_out, d_b_out = ops.gemm_tn_colsum(hs_all[1:n + 1].reshape(n * B, H), D2)
         d_w_hh = gemm_auto(dG2, hs_all[:n].reshape(n * B, H), transA=True)
         # decoder inputs: step 0 = E[x0] (nn.Embedding, padding row 0 has no gradient);
         # step t>0 = val_in[t-1]*E[tok[t-1]] (a dense mm in the reference: no padding semantics, and its
@@ -460,7 +459,7 @@ class _GenDecode(Function):
         sumG = colsum(dG.view(n, B * 4 * H)).view(B, 4 * H)
         d_w_ic = gemm(sumG, ctxt, transA=True)
         d_ctxt = gemm(sumG, w_ic)
-        d_b = colsum(dG2)
+        d_b = colsum(sumG)                       # = colsum(dG2): the [B, 4H] sums over time are there already
         d_w_ih = torch.cat([d_w_ic, d_w_ie], dim=1)
         d_emb = torch.zeros_like(emb_W)
         embed_bwd(tok0, demb_all[0], d_emb, None, 0)

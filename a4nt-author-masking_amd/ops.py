@@ -5,6 +5,7 @@ liba4nt_hip.so and wires the results into torch.autograd.  There is no CPU / eag
 tensor that is not a float32 CUDA tensor is an error.
 """
 import contextlib
+import os
 import ctypes
 import threading
 
@@ -258,6 +259,30 @@ def colsum(A, out=None, accumulate=False):
     ws = torch.empty(nws, device=A.device, dtype=torch.float32) if nws else None
     check(lib.a4nt_colsum(M, N, _p(A), _ld(A), _p(out), int(accumulate), _p(ws), nws, _s()), 'a4nt_colsum')
     return out
+
+
+def gemm_tn_colsum(A, B):
+    """(A^T @ B, column sums of B) for A [K,M], B [K,N]: weight and bias gradient of y = x W + b from x and dy in one
+    pass over dy (a4nt_sgemm_tn_colsum; split-K as gemm_auto picks it).  Few-tile outputs take the two separate calls."""
+    lib = _lib.load()
+    A = _rowmajor(_f32(A, 'gemm_tn_colsum A'))
+    B = _rowmajor(_f32(B, 'gemm_tn_colsum B'))
+    K, M = A.shape
+    N = B.shape[1]
+    if B.shape[0] != K:
+        raise A4NTError('gemm_tn_colsum: inner dimensions differ (%d vs %d)' % (K, B.shape[0]))
+    ks = _auto_ksplit(M, N, K)
+    if not TN_COLSUM or K == 0 or lib.a4nt_sgemm_tile(M, N, ks) != 128:
+        return gemm_auto(A, B, transA=True), colsum(B)
+    out = torch.empty((ks, M, N) if ks > 1 else (M, N), device=A.device, dtype=torch.float32)
+    colpart = torch.empty((ks, N), device=A.device, dtype=torch.float32)
+    with _Timed('sgemm_tn_128' if TIMER is not None else None, 2.0 * M * N * K):
+        check(lib.a4nt_sgemm_tn_colsum(M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), N, ks, M * N if ks > 1 else 0,
+                                       _p(colpart), _s()), 'a4nt_sgemm_tn_colsum')
+    return (slab_reduce(out) if ks > 1 else out), (colsum(colpart) if ks > 1 else colpart[0])
+
+
+TN_COLSUM = os.environ.get('A4NT_TN_COLSUM', '1') != '0'   # 0: gemm_tn_colsum runs the product and a4nt_colsum separately (A/B runs)
 
 
 def embed_fwd(ids, W, scale=None):
@@ -533,8 +558,11 @@ class _LinearKN(Function):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
         dx = gemm_auto(dy, W, transB=True) if ctx.needs_input_grad[0] else None
-        dW = gemm_auto(x, dy, transA=True) if ctx.needs_input_grad[1] else None
-        db = colsum(dy) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        if ctx.needs_input_grad[1] and ctx.has_b and ctx.needs_input_grad[2]:
+            dW, db = gemm_tn_colsum(x, dy)
+        else:
+            dW = gemm_auto(x, dy, transA=True) if ctx.needs_input_grad[1] else None
+            db = colsum(dy) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         return dx, dW, db
 
 
@@ -942,8 +970,11 @@ class _ProjNLL(Function):
         h, W, dlogits = ctx.saved_tensors
         # [N,V] x [V,H]: few output tiles over a long K -- the split-K model picks 3 slabs at N=12800 (1.35 -> 1.08 ms)
         dh = gemm_auto(dlogits, W, transB=True) if ctx.needs_input_grad[0] else None
-        dW = gemm_auto(h, dlogits, transA=True) if ctx.needs_input_grad[1] else None
-        db = colsum(dlogits) if ctx.needs_input_grad[2] else None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            dW, db = gemm_tn_colsum(h, dlogits)        # d(logits) is staged once for both
+        else:
+            dW = gemm_auto(h, dlogits, transA=True) if ctx.needs_input_grad[1] else None
+            db = colsum(dlogits) if ctx.needs_input_grad[2] else None
         return (dh * g if dh is not None else None, dW * g if dW is not None else None,
                 db * g if db is not None else None, None, None)
 

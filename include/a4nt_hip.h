@@ -358,6 +358,15 @@ int a4nt_embed_bwd(long long N, int E, int V, const long long* ids, const float*
 long long a4nt_colsum_ws_floats(int M, int N);
 int a4nt_colsum(int M, int N, const float* A, int lda, float* out, int accumulate, float* ws, long long ws_floats,
                 void* stream);
+/* Weight and bias gradient of a linear layer in one pass: C[M,N] = A^T * B with A stored [K][M] and B stored [K][N]
+ * (the transA=1, transB=0 case of a4nt_sgemm on 128x128 tiles, same ksplit / slab_stride meaning), and
+ * colpart[z][n] = sum over K slab z of B[k][n], taken from the B tiles as they are staged for the product, so the
+ * [K,N] matrix (the d(logits) of the output layer: K = tokens, N = vocabulary) is not read a second time for
+ * a4nt_colsum.  colpart holds ksplit * N floats; the caller adds the ksplit rows (a4nt_colsum over [ksplit][N]).
+ * Shapes whose output is a few tiles only (a4nt_sgemm_tile(M, N, ksplit) != 128) are refused: A4NT_ERR_ARG.
+ * Replaces: autograd's backward of dec_out.mm(decoder_W) + decoder_b for W and b together (char_translator.py:279,377). */
+int a4nt_sgemm_tn_colsum(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                         int ksplit, long long slab_stride, float* colpart, void* stream);
 /* out[r][c] = sum_s slabs[s*stride + r*lds + c0 + c] (+ add[r][c])  (split-K reduction). */
 int a4nt_slab_reduce(int S, long long stride, int R, int C, const float* slabs, int lds, int c0, const float* add,
                      int lda, float* out, int ldo, void* stream);

@@ -148,6 +148,36 @@ def test_sgemm_splitk(ops):
     assert_close(ops.gemm_auto(A.cuda(), B.cuda(), transB=True), ref.float(), 2e-6, 'gemm_auto')
 
 
+@pytest.mark.parametrize('M,N,K', [(512, 10001, 3200), (512, 10001, 1037), (2048, 2048, 600), (500, 3001, 2050),
+                                   (1024, 30001, 700), (64, 100, 50)])
+def test_sgemm_tn_colsum(ops, M, N, K):
+    """Weight gradient x^T dy and bias gradient sum_k dy[k] from one pass over dy: ragged M / N / K edges, split-K
+    (the [512 x 10001] shapes split 2- or 3-fold), a strided dy, and the few-tile shape that takes the separate calls."""
+    from a4nt_amd import _lib
+    A, B = _rand(K, M, seed=91), _rand(K, N, seed=92)
+    refC, refs = A.double().t() @ B.double(), B.double().sum(0)
+    tol = 2e-6 * max(1.0, (K / 1000.0) ** 0.5)
+    C, s = ops.gemm_tn_colsum(A.cuda(), B.cuda())
+    assert_close(C, refC.float(), tol, 'tn_colsum product')
+    assert_close(s, refs.float(), tol, 'tn_colsum column sums')
+    wide = _rand(K, N + 8, seed=93).cuda()                      # dy as a column window (unaligned rows)
+    wide[:, 3:N + 3] = B.cuda()
+    C2, s2 = ops.gemm_tn_colsum(A.cuda(), wide[:, 3:N + 3])
+    assert torch.equal(C2, C) and torch.equal(s2, s), 'tn_colsum: strided B differs'
+    # the product is the plain TN kernel's, bit for bit (the same tiles in the same order)
+    ks = ops._auto_ksplit(M, N, K)
+    if _lib.load().a4nt_sgemm_tile(M, N, ks) == 128:
+        assert torch.equal(C, ops.gemm_auto(A.cuda(), B.cuda(), transA=True))
+        part = torch.empty(ks * N, device='cuda')
+        rc = _lib.load().a4nt_sgemm_tn_colsum(M, N, K, ops._p(A.cuda()), M, ops._p(B.cuda()), N, ops._p(C), N, 0, 0,
+                                              ops._p(part), None)
+        assert rc != 0, 'ksplit = 0 accepted'
+    else:
+        rc = _lib.load().a4nt_sgemm_tn_colsum(M, N, K, ops._p(A.cuda()), M, ops._p(B.cuda()), N, ops._p(C), N, 1, 0,
+                                              ops._p(s), None)
+        assert rc != 0, 'few-tile shape accepted'
+
+
 @pytest.mark.parametrize('V', [50, 2048, 2049, 3000, 10001, 10240, 10241, 12000, 16384, 16385, 30001, 32768, 32769, 40000])   # incl. the kernel selection edges
 @pytest.mark.parametrize('inplace', [False, True])
 def test_gumbel_bwd_rows(ops, V, inplace):

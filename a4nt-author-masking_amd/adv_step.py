@@ -322,6 +322,7 @@ class GradAllReducer(object):
         wire = flat.cpu() if (self.host_staged and flat.is_cuda) else flat
         work = self.dist.all_reduce(wire, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, flat, wire))
+        ops.COLLECTIVES_IN_FLIGHT += 1       # sweeps queued from here to wait() may run beside the collective's kernels
 
     # -- common ---------------------------------------------------------------------------------
     def launch(self):
@@ -364,6 +365,7 @@ class GradAllReducer(object):
             # parameters this pass never produced a gradient for (their slices travelled as zeros on every rank)
             for i in self._was_none - set(self._seen):
                 self.params[i].grad = None
+        ops.COLLECTIVES_IN_FLIGHT -= len(self._pending)
         self._pending = []
 
     def all_reduce_scalars(self, t):

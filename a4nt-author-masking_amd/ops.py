@@ -372,6 +372,14 @@ _MAX_WGS = {}      # device index -> budget set through lstm_set_max_workgroups 
 # sweeps -- no collective is in flight then: every exchange is waited for before the optimizer step -- keep two
 # workgroups per CU.
 BWD_MAX_WGS = None
+# BWD_MAX_WGS applies only to sweeps that are QUEUED while a gradient all-reduce is in flight (issued, not yet waited
+# for: adv_step.GradAllReducer counts them in COLLECTIVES_IN_FLIGHT).  A collective starts behind everything queued
+# on the compute stream before it was issued and is waited for before the optimizer step, so only the sweeps queued
+# in between can share the chip with its kernels: the BPTT sweeps in front of the first complete bucket keep two
+# workgroups per CU.  False: every backward sweep takes BWD_MAX_WGS.
+BWD_BUDGET_DYNAMIC = os.environ.get('A4NT_BWD_BUDGET_DYNAMIC', '1') != '0'
+COLLECTIVES_IN_FLIGHT = 0
+BWD_BUDGET_STATS = {'switched': 0, 'kept': 0}       # backward launches under BWD_MAX_WGS: with / without the switch
 
 
 @contextlib.contextmanager
@@ -385,6 +393,11 @@ def _bwd_budget():
     if n is None or int(n) == mine:
         yield
         return
+    if BWD_BUDGET_DYNAMIC and COLLECTIVES_IN_FLIGHT <= 0:
+        BWD_BUDGET_STATS['kept'] += 1
+        yield
+        return
+    BWD_BUDGET_STATS['switched'] += 1
     lib = _lib.load()
     check(lib.a4nt_lstm_set_max_workgroups(int(n)), 'a4nt_lstm_set_max_workgroups')
     try:

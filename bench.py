@@ -372,8 +372,10 @@ def main():
     elif world > 1 or args.dp_rehearsal:
         # leave half of every CU's registers to the RCCL kernels that run beside the persistent LSTM sweeps.  On the
         # fused path every exchange has been waited for before the next forward pass starts (the gradient buckets
-        # travel under the BACKWARD passes only), so the forward sweeps keep two workgroups per CU; with two
-        # generation passes the discriminator's exchange runs under the generator's encoder sweeps: one per CU throughout
+        # travel under the BACKWARD passes only), so the forward sweeps keep two workgroups per CU, and so do the
+        # backward sweeps queued before the pass's first bucket goes out (ops.BWD_BUDGET_DYNAMIC: the budget applies
+        # while a collective is in flight); with two generation passes the discriminator's exchange runs under the
+        # generator's encoder sweeps: one per CU throughout
         if args.separate_gen:
             impl.lstm_set_max_workgroups(256)
         else:

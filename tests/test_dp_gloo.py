@@ -31,7 +31,7 @@ def _worker(rank, world, port, out_q, overlap):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import oracle
-    from a4nt_amd import GradAllReducer
+    from a4nt_amd import GradAllReducer, ops
     torch.manual_seed(0)
     m = oracle.CharLstm(EP)
     x, y = _data()
@@ -44,8 +44,12 @@ def _worker(rank, world, port, out_q, overlap):
         red.arm()
         F.cross_entropy(logits, y[sh]).backward()
         issued_early.append(len(red._pending))
+        # the count that steers the backward sweeps' workgroup budget (ops.BWD_MAX_WGS) follows the exchange
+        assert ops.COLLECTIVES_IN_FLIGHT == len(red._pending)
         red.launch()
+        assert ops.COLLECTIVES_IN_FLIGHT == len(red._pending) > 0
         red.wait()
+        assert ops.COLLECTIVES_IN_FLIGHT == 0
     cnt = red.all_reduce_scalars(torch.tensor([1.0 + rank, 10.0]))
     w_tok = float(red.token_weight(10 if rank == 0 else 30))
     if rank == 0:

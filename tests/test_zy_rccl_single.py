@@ -24,7 +24,8 @@ def _child(port, q):
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     import a4nt_amd as impl
-    impl.lstm_set_max_workgroups(256)
+    from a4nt_amd import ops
+    ops.BWD_MAX_WGS = 256            # bench.py's data-parallel setting: backward sweeps queued beside a collective: one per CU
     src, tgt, gb, noise = _inputs()
     res = {}
     for mode in ('plain', 'rccl'):
@@ -40,6 +41,12 @@ def _child(port, q):
         if mode == 'rccl':
             cnt = reds[1].all_reduce_scalars(torch.tensor([3.0, 4.0], device='cuda'))
             assert cnt.tolist() == [3.0, 4.0]
+            # the budget switch follows the collectives: sweeps queued in front of the first complete bucket kept the
+            # device's own budget, those queued behind it took BWD_MAX_WGS, and nothing is left in flight
+            assert ops.COLLECTIVES_IN_FLIGHT == 0, ops.COLLECTIVES_IN_FLIGHT
+            assert ops.BWD_BUDGET_STATS['switched'] > 0 and ops.BWD_BUDGET_STATS['kept'] > 0, ops.BWD_BUDGET_STATS
+        else:
+            assert ops.BWD_BUDGET_STATS['switched'] == 0, ops.BWD_BUDGET_STATS      # no collective, no switch
         impl.check_timeouts()
         torch.cuda.synchronize()
         res[mode] = ({n: p.grad.cpu().numpy() for n, p in G.named_parameters()},

@@ -13,7 +13,7 @@ from a4nt_amd import _lib
 
 lib = _lib.load()
 log = []
-orig, orig_nll = lib.a4nt_sgemm, lib.a4nt_sgemm_nll
+orig, orig_nll, orig_cs = lib.a4nt_sgemm, lib.a4nt_sgemm_nll, lib.a4nt_sgemm_tn_colsum
 
 
 def wrap(tA, tB, M, N, K, *rest):
@@ -26,8 +26,12 @@ def wrap_nll(M, N, K, *rest):
     return orig_nll(M, N, K, *rest)
 
 
+def wrap_cs(M, N, K, *rest):
+    log.append(('tn_colsum', 1, 0, M, N, K, rest[6]))
+    return orig_cs(M, N, K, *rest)
 
-lib.a4nt_sgemm, lib.a4nt_sgemm_nll = wrap, wrap_nll
+
+lib.a4nt_sgemm, lib.a4nt_sgemm_nll, lib.a4nt_sgemm_tn_colsum = wrap, wrap_nll, wrap_cs
 torch.manual_seed(0)
 batch = 128
 G = impl.CharTranslator(bench.gen_params(batch)).cuda().train()

@@ -13,7 +13,8 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 NAMES = [(r'sgemm_kernel<false, false, 2, 2, \d, 1, true', 'sgemm_nn_128_nll'),
-         (r'sgemm_kernel<false, true, 2', 'sgemm_nt_128'), (r'sgemm_kernel<true, false, 2', 'sgemm_tn_128'),
+         (r'sgemm_kernel<false, true, 2', 'sgemm_nt_128'), (r'sgemm_kernel<true, false, 2, 2, \d, 1, false, true', 'sgemm_tn_128_colsum'),
+         (r'sgemm_kernel<true, false, 2', 'sgemm_tn_128'),
          (r'sgemm_kernel<false, false, 2', 'sgemm_nn_128'), (r'sgemm_kernel<.*, 1, 1, 4', 'sgemm_64'),
          (r'lstm_fwd2_kernel', 'lstm_fwd_pair'), (r'lstm_bwdx2_kernel|lstm_bwd2_kernel', 'lstm_bwd_pair'),
          (r'lstm_dec_kernel', 'lstm_dec_step'), (r'lstm_fwd_kernel', 'lstm_fwd'),

@@ -21,7 +21,7 @@ import sys
 from collections import defaultdict
 
 LABELS = [
-    (r'sgemm_kernel<(true|false), (true|false), (\d), \d, \d(?:, \d)?(?:, (?:true|false))?>', None),
+    (r'sgemm_kernel<(true|false), (true|false), (\d), \d, \d(?:, \d)?(?:, (true|false))?(?:, (true|false))?>', None),
     (r'lstm_fwd2_kernel', 'lstm_seq_fwd_pair'),
     (r'lstm_bwdx2_kernel|lstm_bwd2_kernel', 'lstm_seq_bwd_pair'),
     (r'nt_rows_kernel', 'sgemm_nt_rows'),
@@ -44,7 +44,8 @@ def label_of(name):
     m = re.search(LABELS[0][0], name)
     if m:
         ta, tb, w = m.group(1) == 'true', m.group(2) == 'true', int(m.group(3))
-        nll = '_nll' if re.search(r', true>', name[m.start():m.end()]) and not ta and not tb and name[m.start():m.end()].count(',') >= 6 else ''
+        nll = '_nll' if m.group(4) == 'true' else ''        # 7th template argument: NLL epilogue; 8th: column sums of B
+        nll += '_colsum' if m.group(5) == 'true' else ''
         return 'sgemm_%s_%d%s' % ('tn' if ta else ('nt' if tb else 'nn'), 128 if w == 2 else 64, nll)
     for pat, lab in LABELS[1:]:
         if re.search(pat, name):

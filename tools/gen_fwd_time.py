@@ -92,3 +92,29 @@ for B in (256, 128):
             print('   %s (share of its step, x %.1f us):' % (name, ms * 1000.0 / n_max))
             for lb, x in zip(labels, v):
                 print('      %-32s %5.1f %%  %6.2f us' % (lb, 100.0 * x / tot, x / tot * ms * 1000.0 / n_max))
+
+# The same loop replayed from a captured graph (hipGraph through torch.cuda.CUDAGraph): does the GPU run the 200
+# dependent launches of a generation closer together when they come from one graph launch?
+if os.environ.get('A4NT_GRAPH', '1') != '0':
+    for B in (256, 128):
+        fa, keep = make(B, B)
+        run(fa, main)
+        torch.cuda.synchronize()
+        ref_tok = keep['tok'].clone()
+        ms_direct = timed(lambda: run(fa, main), reps=10)
+        side = torch.cuda.Stream()
+        side.wait_stream(main)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            run(fa, side)                                # warm-up on the capture stream
+            side.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                run(fa, torch.cuda.current_stream())
+        main.wait_stream(side)
+        keep['tok'].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ref_tok, keep['tok']))
+        ms_graph = timed(graph.replay, reps=10)
+        print('generation forward, %d rows: direct %.3f ms, graph replay %.3f ms (%.1f vs %.1f us per step), tokens equal: %s'
+              % (B, ms_direct, ms_graph, ms_direct * 10.0, ms_graph * 10.0, same))

@@ -39,7 +39,9 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
             modelGen.train()
         samples, gen_lens, char_outs = modelGen.forward_advers_gen(
             inps, lens, soft_samples=True, end_c=end_c, n_max=maxlen, temp=temp, auths=1 - auths, compact=True)
-    if before_disc is not None:
+    ml_cycle = cycle_compute and backprop_for != 'eval' and cycle_loss_type == 'ml'
+    late_disc = before_disc is not None and ml_cycle and real_batch is None
+    if before_disc is not None and not late_disc:
         before_disc()                   # e.g. the deferred discriminator step: the generation above did not need it
     if grad_filter:
         samples.set_grad_filter()
@@ -55,15 +57,23 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
     drop = backprop_for == 'eval'
     real_out = None
     cyc = None
-    ml_cycle = cycle_compute and backprop_for != 'eval' and cycle_loss_type == 'ml'
     if ml_cycle and real_batch is None:
         # The discriminator over the generated batch and the reconstruction pass over the same batch do not use
         # each other's results: their LSTM layers are launched pairwise (ops.paired), forward and backward.
         reverse_inp = samples_srt.prepend_token(_start_id(append_symb))
-        eval_out, cyc = ops.paired(
-            lambda: modelEval.forward_classify(samples_srt, adv_inp=True, lens=len_sorted.tolist(), drop=drop),
-            lambda: modelGen.forward_mltrain_loss(reverse_inp, len_sorted.tolist(), inps, lens, targs, auths=auths,
-                                                  adv_inp=True, sort_enc=rev_dev))
+        f_disc = lambda: modelEval.forward_classify(samples_srt, adv_inp=True, lens=len_sorted.tolist(), drop=drop)
+        f_cyc = lambda: modelGen.forward_mltrain_loss(reverse_inp, len_sorted.tolist(), inps, lens, targs, auths=auths,
+                                                      adv_inp=True, sort_enc=rev_dev)
+        if late_disc:
+            # A deferred discriminator step (its gradient exchange still in flight): the reconstruction pass goes
+            # first and queues everything in front of its first sweep (sample embedding, input-gate product) before
+            # the discriminator branch waits for the exchange and steps -- that work runs beside the all-reduce
+            def f_disc_late():
+                before_disc()
+                return f_disc()
+            cyc, eval_out = ops.paired(f_cyc, f_disc_late)
+        else:
+            eval_out, cyc = ops.paired(f_disc, f_cyc)
     elif real_batch is not None and hasattr(modelEval, 'forward_classify_multi'):
         eval_out, real_out = modelEval.forward_classify_multi(
             [(samples_srt, len_sorted.tolist(), True), (real_batch[0], real_batch[1], False)], drop=drop)
@@ -615,11 +625,15 @@ def fused_update(modelGen, modelEval, optimGen, optimEval, src_batch, tgt_batch,
     lens_g = ops.attach_host_lens(gen_lens[B:], gl[B:])
     gen_d = (samples.rows(0, B, n_d, differentiable=False), lens_d, list(tok[:n_d, :B].unbind(0)))
     gen_g = (samples.rows(B, 2 * B, n_g), lens_g, list(tok[:n_g, B:].unbind(0)))
+    # Data parallel: the discriminator's exchange and optimizer step are deferred into the generator update, which
+    # runs them right before it first reads the discriminator -- behind the reconstruction pass's first products
+    # (adv_forward_pass, late_disc).  Single process: nothing is in flight, the step is finished here as before.
+    defer = reducers[1] is not None and reducers[1].on
     rd = d_update(modelGen, modelEval, optimEval, src_batch, tgt_batch, c_aid, end_c, maxlen, temp, step=step,
-                  reducer=reducers[1], gen=gen_d)
+                  reducer=reducers[1], gen=gen_d, defer=defer)
     rg = g_update(modelGen, modelEval, optimGen, gen_batch, c_aid, end_c, maxlen, temp, append_symb,
                   cycle_loss_type=cycle_loss_type, cycle_loss_w=cycle_loss_w, grad_clip=grad_clip, step=step,
-                  reducer=reducers[0], gen=gen_g)
+                  reducer=reducers[0], gen=gen_g, before_disc=rd.pop('finish') if defer else None)
     return rd, rg
 
 

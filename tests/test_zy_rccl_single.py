@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from test_zz_dp_gpu import _inputs, _models, _step          # same shapes and inputs as the two-rank gloo test
+from test_zz_dp_gpu import T, _inputs, _models, _step          # same shapes and inputs as the two-rank gloo test
 
 
 def _child(port, q):
@@ -52,6 +52,24 @@ def _child(port, q):
         res[mode] = ({n: p.grad.cpu().numpy() for n, p in G.named_parameters()},
                      {n: p.grad.cpu().numpy() for n, p in D.named_parameters()}, float(out[1]['grad_norm']),
                      float(out[1]['cyc_loss']))
+        # two STEPPING updates: under a process group the discriminator's exchange + optimizer step are deferred into
+        # the generator update (behind the reconstruction pass's first products); the weights must come out as in the
+        # plain step, where the discriminator is stepped before the generator update starts
+        G2, D2 = _models(impl)
+        reds2 = (None, None)
+        if mode == 'rccl':
+            reds2 = (impl.GradAllReducer(list(G2.parameters()), bucket_mb=0.01, force=True),
+                     impl.GradAllReducer(list(D2.parameters()), bucket_mb=0.01, force=True))
+        optG, optD = impl.make_optimizers(G2, D2)
+        for it in range(2):
+            G2.set_noise([u.cuda() for u in noise])
+            impl.fused_update(G2, D2, optG, optD, src, tgt, gb, 0, -1, T, 0.5, 2, cycle_loss_type='ml', step=True,
+                              reducers=reds2)
+        impl.check_timeouts()
+        torch.cuda.synchronize()
+        assert ops.COLLECTIVES_IN_FLIGHT == 0
+        res[mode] = res[mode] + ({'G.' + n: p.detach().cpu().numpy() for n, p in G2.named_parameters()},
+                                 {'D.' + n: p.detach().cpu().numpy() for n, p in D2.named_parameters()})
     dist.destroy_process_group()
     q.put(res)
 
@@ -65,15 +83,25 @@ def test_rccl_group_of_one_equals_plain_step():
     p = ctx.Process(target=_child, args=(29900 + (os.getpid() % 90), q))
     p.start()
     import queue
-    try:
-        res = q.get(timeout=200)
-    except queue.Empty:
-        p.kill()
-        p.join(timeout=30)
-        raise AssertionError('the RCCL single-rank step produced no result within 200 s (exit code %s)' % p.exitcode)
+    import time
+    res, t0 = None, time.time()
+    while res is None:
+        try:
+            res = q.get(timeout=5)
+        except queue.Empty:
+            if not p.is_alive():        # the child raised: fail now, with its exit code (its traceback is on stderr)
+                raise AssertionError('the RCCL single-rank child exited with code %s without a result' % p.exitcode)
+            if time.time() - t0 > 200:
+                p.kill()
+                p.join(timeout=30)
+                raise AssertionError('the RCCL single-rank step produced no result within 200 s')
     p.join(timeout=60)
     assert p.exitcode == 0
-    (gG, gD, gn, cyc), (rG, rD, rn, rcyc) = res['plain'], res['rccl']
+    (gG, gD, gn, cyc, wG, wD), (rG, rD, rn, rcyc, vG, vD) = res['plain'], res['rccl']
+    for a, b in ((wG, vG), (wD, vD)):           # weights after two stepping updates (a misplaced step shows as ~1e-2)
+        assert set(a) == set(b)
+        for k in a:
+            assert np.abs(a[k] - b[k]).max() <= 2e-5 * max(np.abs(a[k]).max(), 1e-30), k
     assert cyc == rcyc and abs(gn - rn) <= 1e-6 * abs(gn)
     for a, b in ((gG, rG), (gD, rD)):
         assert set(a) == set(b)

@@ -107,9 +107,20 @@ def test_two_ranks_on_one_gpu_equal_single_process():
     for p in procs:
         p.start()
     import queue
-    try:
-        gG, gD, gnorm = q.get(timeout=90)
-    except queue.Empty:
+    import time
+    got, t0 = None, time.time()
+    while got is None and time.time() - t0 < 90:
+        try:
+            got = q.get(timeout=3)
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead:                    # a rank raised (its traceback is on stderr): not a hang, fail at once
+                for p in procs:
+                    p.kill()
+                raise AssertionError('a data-parallel rank exited with code %s without a result' % dead)
+    if got is not None:
+        gG, gD, gnorm = got
+    else:
         # A hang is a failure: a deadlock in GradAllReducer, two processes' persistent sweeps that are not co-resident,
         # or gloo not completing async all-reduces of CUDA tensors on a busy GPU (seen with plain torch matmuls,
         # DESIGN.md section 7) all look the same from here; the ranks' stacks (faulthandler, 75 s) tell them apart.

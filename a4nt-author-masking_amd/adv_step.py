@@ -40,7 +40,9 @@ def adv_forward_pass(modelGen, modelEval, inps, lens, end_c=0, backprop_for='all
         samples, gen_lens, char_outs = modelGen.forward_advers_gen(
             inps, lens, soft_samples=True, end_c=end_c, n_max=maxlen, temp=temp, auths=1 - auths, compact=True)
     ml_cycle = cycle_compute and backprop_for != 'eval' and cycle_loss_type == 'ml'
-    late_disc = before_disc is not None and ml_cycle and real_batch is None
+    # (only when paired() really interleaves: run one after the other, the reconstruction pass would launch its
+    # forward sweeps, two workgroups per CU, beside the collective that is still in flight)
+    late_disc = before_disc is not None and ml_cycle and real_batch is None and ops.pairing_available()
     if before_disc is not None and not late_disc:
         before_disc()                   # e.g. the deferred discriminator step: the generation above did not need it
     if grad_filter:

@@ -932,6 +932,11 @@ def paired(fn0, fn1):
 PAIR_LSTM = True
 
 
+def pairing_available():
+    """True when paired() would interleave its two computations (not switched off, not already inside a pair)."""
+    return bool(PAIR_LSTM) and getattr(_pair_local, 'sched', None) is None
+
+
 class _Embed(Function):
     """nn.Embedding lookup with padding_idx semantics (zero gradient for the padding row)."""
 

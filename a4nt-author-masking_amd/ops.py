@@ -276,7 +276,7 @@ def gemm_tn_colsum(A, B):
         return gemm_auto(A, B, transA=True), colsum(B)
     out = torch.empty((ks, M, N) if ks > 1 else (M, N), device=A.device, dtype=torch.float32)
     colpart = torch.empty((ks, N), device=A.device, dtype=torch.float32)
-    with _Timed('sgemm_tn_128' if TIMER is not None else None, 2.0 * M * N * K):
+    with _Timed('sgemm_tn_128_colsum' if TIMER is not None else None, 2.0 * M * N * K):
         check(lib.a4nt_sgemm_tn_colsum(M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), N, ks, M * N if ks > 1 else 0,
                                        _p(colpart), _s()), 'a4nt_sgemm_tn_colsum')
     return (slab_reduce(out) if ks > 1 else out), (colsum(colpart) if ks > 1 else colpart[0])

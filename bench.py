@@ -187,6 +187,7 @@ def _latest_profile(stem, workload='adv'):
 
 
 _KERNEL_LABELS = (                       # rocprofv3 kernel name prefix -> ops._Timed label
+    ('void sgemm_kernel<true, false, 2, 2, 2, 1, false, true>', 'sgemm_tn_128_colsum'),
     ('void sgemm_kernel<true, false, 2, 2,', 'sgemm_tn_128'), ('void sgemm_kernel<false, true, 2, 2,', 'sgemm_nt_128'),
     ('void sgemm_kernel<false, false, 2, 2,', 'sgemm_nn_128'), ('void sgemm_kernel<false, true, 1, 1,', 'sgemm_nt_64'),
     ('void proj_gumbel_kernel', 'proj_gumbel'), ('void lstm_fwd', 'lstm_seq_fwd'), ('void lstm_bwd', 'lstm_seq_bwd'))

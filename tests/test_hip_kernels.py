@@ -391,8 +391,10 @@ def test_lstm_backward_budget(ops):
     xa, xb = _rand(T, 128, I, seed=52).cuda(), _rand(T, 128, I, seed=53).cuda()
     up, upa = _rand(T, B, H, seed=54).cuda(), _rand(T, 128, H, seed=55).cuda()
     res = {}
+    dyn = ops.BWD_BUDGET_DYNAMIC
     for mode in (None, 256):
         ops.BWD_MAX_WGS = mode
+        ops.BWD_BUDGET_DYNAMIC = False       # the budget on every backward sweep (no collective in flight here)
         try:
             for v in list(P.values()) + [x]:
                 v.grad = None
@@ -402,8 +404,28 @@ def test_lstm_backward_budget(ops):
             (l0 + la + 2 * lb).backward()
             ops.check_timeouts()
             res[mode] = [l0.detach(), la.detach(), lb.detach(), x.grad.clone()] + [P[k].grad.clone() for k in sorted(P)]
+            if mode == 256:
+                # dynamic rule: without a collective in flight the same pass keeps the device's own budget ...
+                ops.BWD_BUDGET_DYNAMIC = True
+                kept, sw = ops.BWD_BUDGET_STATS['kept'], ops.BWD_BUDGET_STATS['switched']
+                for v in list(P.values()) + [x]:
+                    v.grad = None
+                _stack_loss(ops, P, x, None, up).backward()
+                assert ops.BWD_BUDGET_STATS['kept'] > kept and ops.BWD_BUDGET_STATS['switched'] == sw
+                assert torch.equal(x.grad, res[None][3])             # ... i.e. the default geometry's bits
+                # ... and takes BWD_MAX_WGS while one is counted
+                ops.COLLECTIVES_IN_FLIGHT += 1
+                try:
+                    for v in list(P.values()) + [x]:
+                        v.grad = None
+                    _stack_loss(ops, P, x, None, up).backward()
+                finally:
+                    ops.COLLECTIVES_IN_FLIGHT -= 1
+                assert ops.BWD_BUDGET_STATS['switched'] > sw
+                ops.check_timeouts()
         finally:
             ops.BWD_MAX_WGS = None
+            ops.BWD_BUDGET_DYNAMIC = dyn
     for a, b in zip(res[None][:3], res[256][:3]):
         assert torch.equal(a, b)                                     # forward passes: the same kernels
     for a, b in zip(res[None][3:], res[256][3:]):
@@ -419,7 +441,9 @@ def test_lstm_workspace_follows_geometry(ops):
     x = _rand(T, B, I, seed=61).cuda().requires_grad_(True)
     up = _rand(T, B, H, seed=62).cuda()
     first = {}
+    dyn = ops.BWD_BUDGET_DYNAMIC
     try:
+        ops.BWD_BUDGET_DYNAMIC = False          # the budget on every backward sweep, no collective needed
         for mode in (256, None, 256, None):
             ops.BWD_MAX_WGS = mode
             for v in list(P.values()) + [x]:
@@ -434,6 +458,7 @@ def test_lstm_workspace_follows_geometry(ops):
             first[mode] = got
     finally:
         ops.BWD_MAX_WGS = None
+        ops.BWD_BUDGET_DYNAMIC = dyn
     dev = torch.cuda.current_device()
     mine = {k: v for k, v in ops._ws.items() if k[:4] == (dev, B, H, True) and len(k) == 6}
     assert sorted((k[4], k[5]) for k in mine) == [(1, 16), (2, 8)]

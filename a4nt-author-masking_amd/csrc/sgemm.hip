@@ -112,6 +112,78 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, int m0, int n0, int kb
     }
 }
 
+// Epilogue of one workgroup tile at (m0, n0): C (+)= acc (+ bias), bounds-checked; NLL: per row the (max, sum of exp)
+// of this wave's 32*WN columns into g.part (see a4nt_sgemm_nll).
+// C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+template <int WM, int WN, bool NLL>
+__device__ __forceinline__ void store_tile(const GemmArgs& g, float* C, f32x16 (&acc)[WM][WN], int m0, int n0, int tn,
+                                           int lane, int wave, int wm, int wn, bool add_bias) {
+    float bcol[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int col = n0 + wn + 32 * j + (lane & 31);
+        bcol[j] = (add_bias && col < g.N) ? g.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + wn + 32 * j + (lane & 31);
+            if (col >= g.N) continue;
+            const float bv = bcol[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.M) {
+                    float* dst = C + (long long)row * g.ldc + col;
+                    float v = acc[i][j][r] + bv;
+                    if (g.beta) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    if (NLL) {
+        // log-softmax statistics of the logits just produced, while they are still in the accumulators: per row the
+        // (max, sum of exp relative to it) over this wave's 32*WN columns.  A row of the 32x32 tile lives in one
+        // register index across the 32 lanes of a half wave: butterfly over those lanes.  The row kernel
+        // (a4nt_nll_grad_rows) merges the partials of a row, so the loss needs no pass of its own over the logits.
+        const int p = tn * 2 + (wave & 1);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v[WN];
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int col = n0 + wn + 32 * j + (lane & 31);
+                    v[j] = col < g.N ? acc[i][j][r] + bcol[j] : -INFINITY;
+                    m = fmaxf(m, v[j]);
+                }
+                // over the 32 lanes of the half wave: the xor-16 partner through the crossbar, then DPP rotations inside
+                // the 16-lane rows (lane 0 of a row: the same operands in the same order as the xor butterfly)
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, pg_dpp_f<PG_ROR(8)>(m));
+                m = fmaxf(m, pg_dpp_f<PG_ROR(4)>(m));
+                m = fmaxf(m, pg_dpp_f<PG_ROR(2)>(m));
+                m = fmaxf(m, pg_dpp_f<PG_ROR(1)>(m));
+                float e = 0.f;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) e += (v[j] == -INFINITY) ? 0.f : expf(v[j] - m);
+                e += __shfl_xor(e, 16);
+                e += pg_dpp_f<PG_ROR(8)>(e);
+                e += pg_dpp_f<PG_ROR(4)>(e);
+                e += pg_dpp_f<PG_ROR(2)>(e);
+                e += pg_dpp_f<PG_ROR(1)>(e);
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if ((lane & 31) == 0 && row < g.M) {
+                    float* q = g.part + ((long long)row * g.nparts + p) * 2;
+                    q[0] = m; q[1] = e;
+                }
+            }
+    }
+}
+
 template <bool TA, bool TB, int WM, int WN, int PF, int KG, bool NLL = false, bool CS = false>
 __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
     static_assert(!CS || (!TB && KG == 1 && WN == 2), "column sums: B stored [K][N], 128-wide tiles");
@@ -210,72 +282,7 @@ __global__ __launch_bounds__(256 * KG) void sgemm_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[0][0][r] += red[((q * 4 + wave) * 16 + r) * 64 + lane];
     }
 
-    // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const bool add_bias = (g.bias != nullptr) && (zz == 0);
-    float bcol[WN];
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int col = n0 + wn + 32 * j + (lane & 31);
-        bcol[j] = (add_bias && col < g.N) ? g.bias[col] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + wn + 32 * j + (lane & 31);
-            if (col >= g.N) continue;
-            const float bv = bcol[j];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < g.M) {
-                    float* dst = C + (long long)row * g.ldc + col;
-                    float v = acc[i][j][r] + bv;
-                    if (g.beta) v += *dst;
-                    *dst = v;
-                }
-            }
-        }
-    if (NLL) {
-        // log-softmax statistics of the logits just produced, while they are still in the accumulators: per row the
-        // (max, sum of exp relative to it) over this wave's 32*WN columns.  A row of the 32x32 tile lives in one
-        // register index across the 32 lanes of a half wave: butterfly over those lanes.  The row kernel
-        // (a4nt_nll_grad_rows) merges the partials of a row, so the loss needs no pass of its own over the logits.
-        const int p = tn * 2 + (wave & 1);
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v[WN];
-                float m = -INFINITY;
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    const int col = n0 + wn + 32 * j + (lane & 31);
-                    v[j] = col < g.N ? acc[i][j][r] + bcol[j] : -INFINITY;
-                    m = fmaxf(m, v[j]);
-                }
-                // over the 32 lanes of the half wave: the xor-16 partner through the crossbar, then DPP rotations inside
-                // the 16-lane rows (lane 0 of a row: the same operands in the same order as the xor butterfly)
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, pg_dpp_f<PG_ROR(8)>(m));
-                m = fmaxf(m, pg_dpp_f<PG_ROR(4)>(m));
-                m = fmaxf(m, pg_dpp_f<PG_ROR(2)>(m));
-                m = fmaxf(m, pg_dpp_f<PG_ROR(1)>(m));
-                float e = 0.f;
-#pragma unroll
-                for (int j = 0; j < WN; ++j) e += (v[j] == -INFINITY) ? 0.f : expf(v[j] - m);
-                e += __shfl_xor(e, 16);
-                e += pg_dpp_f<PG_ROR(8)>(e);
-                e += pg_dpp_f<PG_ROR(4)>(e);
-                e += pg_dpp_f<PG_ROR(2)>(e);
-                e += pg_dpp_f<PG_ROR(1)>(e);
-                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if ((lane & 31) == 0 && row < g.M) {
-                    float* q = g.part + ((long long)row * g.nparts + p) * 2;
-                    q[0] = m; q[1] = e;
-                }
-            }
-    }
+    store_tile<WM, WN, NLL>(g, C, acc, m0, n0, tn, lane, wave, wm, wn, (g.bias != nullptr) && (zz == 0));
 }
 
 template <bool TA, bool TB, int WM, int WN, int PF, int KG = 1>
